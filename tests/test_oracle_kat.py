@@ -1,0 +1,259 @@
+"""Pins the CPU oracle.
+
+* PRG: against the real reference PRgenerator compiled from the reference's own sources
+  (oracle/_ref, present when built in the development container) and against the known-answer
+  words recorded from the compiled reference.
+* Engines: against the share checksums recorded from the compiled reference for the 64x64 ABY3 and
+  SecureNN matmuls and the SecureNN msb at n = 1000 (FNV-1a-64 over row-major words), and against the
+  algebraic properties the reference's own tests assert (test/test_ABY3.cpp, test/test_securenn.cpp).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import protocols as pr
+from oracle_lib import KEY01, KEY12, KEY20, KEYS, fnv1a64, oracle, prg_buff, prg_pops, ref_prg
+
+GOLD = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_goldens.json")))
+
+H = lambda a: [f"{int(x) & 0xFFFFFFFFFFFFFFFF:016X}" for x in a]
+
+PRG_KAT = {
+    KEYS: dict(buf=["BB98853A1E92122E", "CB0E97B81787EF9A", "964C60E2F2ECDDF9", "6073EFD5A383AFDB"],
+               last="AE31F63014553F3C", st=["A2FB52B4F053DFF3", "678075DF2C65C1CA", "81BF28ACBCD01941"],
+               pops=["3C4085387253A1AC", "C93CB0C85E3856D8", "EEF894F9714009C7"], bools=[1, 0, 1, 1, 1, 0, 0, 0]),
+    KEY01: dict(buf=["1C5E1D98289DAC55", "3238B75B1A6B40C1", "77490286BD85BA58", "4499128EE338A8C7"],
+                last="151C1AE8AC6D4F11", st=["B8205429FF4F0A34", "FB7CA7AC90460BEA", "E59F72BB50CC4B2A"],
+                pops=["2643CB33EC326FF6", "98BEFDA8E0849415", "64A5D429C2A35948"], bools=[0, 1, 0, 1, 1, 1, 0, 0]),
+    KEY12: dict(buf=["4B09296463815478", "C619A8509104C027", "F0EC1464E3CE63E0", "E55C25B683BEEA6C"],
+                last="26C7B80009B9FFE0", st=["56E4E57F9C303F7E", "F02B30332AC09739", "8019FDB6457AD291"],
+                pops=["F285F81F3C3F5DD4", "D88B5A2CA9E45F8C", "AFD3898A772B0813"], bools=[1, 1, 0, 1, 0, 1, 1, 0]),
+    KEY20: dict(buf=["721DF1BBDACE7584", "6FF0FB95F4E034E0", "6CB909E1C6DCA05D", "B8333A6AF8DAFEE8"],
+                last="803EC258D80CB8EE", st=["3E7E7ACB06AC1F6E", "AC166A59C0926D0C", "15EBD46901660C99"],
+                pops=["DD83E298E5EF1F68", "CC2A8D3F36550F37", "11ADC651DF837531"], bools=[1, 0, 0, 0, 0, 1, 1, 1]),
+}
+
+
+@pytest.mark.parametrize("key", list(PRG_KAT))
+def test_prg_known_answers(key):
+    k = PRG_KAT[key]
+    ints, bools = prg_buff(key, 0, 8)
+    assert H(ints[:4]) == k["buf"]
+    assert list(bools) == k["bools"]
+    assert H(prg_buff(key, 159999, 1)[0]) == [k["last"]]
+    st = np.zeros(3, dtype=np.uint64)
+    oracle().orc_prg_state_at_pop(key, 0, 0, st)
+    assert H(st) == k["st"]
+    assert H(prg_pops(key, 0, 3)) == k["pops"]
+
+
+def test_prg_seed20_pops():
+    assert H(prg_pops(20, 0, 2)) == ["DDEA8FB3D0E8B792", "A1AA9C6611BE413E"]
+
+
+def test_prg_extended_buffer_is_the_pop_stream():
+    # int_buff[BUFF_NUM + i] (extended) is output #(320005 + 2i): the pop stream, every other word
+    ints, bools = prg_buff(KEY01, 160000, 50)
+    pops = prg_pops(KEY01, 0, 100)
+    assert np.array_equal(ints, pops[0::2])
+    assert np.array_equal(bools, (pops[1::2].view(np.uint64) % 2).astype(np.int8))
+
+
+@pytest.mark.parametrize("seed,lcg", [(KEY01, 0), (20, 0), (0x1234567, 99), (2 ** 64 - 1, 2 ** 63)])
+def test_prg_against_reference_build(seed, lcg):
+    ref = ref_prg()
+    if ref is None:
+        pytest.skip("oracle/_ref not built (reference tree absent)")
+    for first, count in ((0, 1000), (4090, 20), (150000, 10000)):
+        a, b = np.zeros(count, np.int64), np.zeros(count, np.int8)
+        ref.ref_prg_buff(seed, lcg, first, count, a, b)
+        oa, ob = prg_buff(seed, first, count, lcg)
+        assert np.array_equal(a, oa) and np.array_equal(b, ob)
+    for first, count in ((0, 5000), (4095, 3), (123457, 1000)):
+        a = np.zeros(count, np.int64)
+        ref.ref_prg_pop(seed, lcg, first, count, a)
+        assert np.array_equal(a, prg_pops(seed, first, count, lcg))
+    st, ost = np.zeros(3, np.uint64), np.zeros(3, np.uint64)
+    ref.ref_prg_state(seed, lcg, 777, st)
+    oracle().orc_prg_state_at_pop(seed, lcg, 777, ost)
+    assert np.array_equal(st, ost)
+
+
+SURVEY_RECORDED = dict(aby3_Z=["3473CCCD688A3FFF", "C4A9DEE976C7CFB9", "018B191BC4F1E74F"], Z_plain="5DA5023936FC8767",
+                       snn_Z=["A15A8E2BD6E9AA09", "3BC7AB9DC794B0A5"], snn_msb=["D786D08BFC881DEA", "9AF07EF58945A8D0"])
+
+
+@pytest.mark.xfail(reason="engine checksums noted during the survey are not reproducible from their documented recipe: "
+                          "even the plaintext product X*Y of the stated inputs (exact big-integer arithmetic, PRG words "
+                          "verified against the real reference PRgenerator) has a different FNV-1a-64", strict=False)
+def test_survey_recorded_engine_checksums(orc):
+    n = 64
+    X, Y = _cfg1_inputs(n)
+    assert f"{fnv1a64(orc.ring_gemm(X, Y, n, n, n)):016X}" == SURVEY_RECORDED["Z_plain"]
+
+
+def _cfg1_inputs(n=64):
+    w = prg_pops(20, 0, 2 * n * n)
+    return w[: n * n].copy(), w[n * n:].copy()
+
+
+def test_aby3_matmul_64_known_answer(orc):
+    """config 1: shares of Z after share_matrix(X), share_matrix(Y), matrix_mul on fresh engines."""
+    n = 64
+    X, Y = _cfg1_inputs(n)
+    w = pr.World(orc)
+    Xs = pr.aby3_share(w, X, n * n)
+    Ys = pr.aby3_share(w, Y, n * n)
+    Zs = pr.aby3_matmul(w, Xs, Ys, n, n, n)
+    g = GOLD["aby3_matmul_64"]
+    assert [f"{fnv1a64(Zs[j][0]):016X}" for j in range(3)] == g["Z_share0"]
+    Z = pr.aby3_reveal(w, Zs)
+    assert f"{fnv1a64(Z[0]):016X}" == g["Z_plain"]
+    assert np.array_equal(Z[0], Z[1]) and np.array_equal(Z[1], Z[2])
+    plain = (X.view(np.uint64).reshape(n, n).astype(object) @ Y.view(np.uint64).reshape(n, n).astype(object))
+    plain = np.array([[int(v) % 2 ** 64 for v in row] for row in plain], dtype=np.uint64)
+    assert np.array_equal(Z[0].view(np.uint64).reshape(n, n), plain)
+
+
+def test_aby3_matmul_layout_invariance(orc):
+    r, l, c = 5, 4, 3  # test/test_ABY3.cpp:119-129 sizes
+    rng = np.random.default_rng(1)
+    X = rng.integers(-2 ** 63, 2 ** 63, r * l, dtype=np.int64)
+    Y = rng.integers(-2 ** 63, 2 ** 63, l * c, dtype=np.int64)
+    w0, w1 = pr.World(orc), pr.World(orc)
+    Z0 = pr.aby3_matmul(w0, pr.aby3_share(w0, X, r * l), pr.aby3_share(w0, Y, l * c), r, l, c, 0)
+    cm = lambda S, a, b: [tuple(np.ascontiguousarray(s.reshape(a, b).T).ravel() for s in sh) for sh in S]
+    Xs, Ys = cm(pr.aby3_share(w1, X, r * l), r, l), cm(pr.aby3_share(w1, Y, l * c), l, c)
+    Z1 = pr.aby3_matmul(w1, Xs, Ys, r, l, c, 1)
+    for j in range(3):
+        assert np.array_equal(Z0[j][0], Z1[j][0])
+
+
+def test_snn_matmul_64_known_answer(orc):
+    n = 64
+    X, Y = _cfg1_inputs(n)
+    w = pr.World(orc)
+    Xs = pr.snn_share(w, X, n * n)
+    Ys = pr.snn_share(w, Y, n * n)
+    Zs = pr.snn_matmul(w, Xs, Ys, n, n, n)
+    g = GOLD["snn_matmul_64"]
+    assert [f"{fnv1a64(Zs[j]):016X}" for j in range(2)] == g["Z_share"]
+    assert f"{fnv1a64(pr.snn_reveal(w, Zs)):016X}" == g["Z_plain"] == GOLD["aby3_matmul_64"]["Z_plain"]
+
+
+def _pc_inputs(n, seed=22, r_minus1_every5=True):
+    """Per element: x = pop, r = pop (r = -1 when i % 5 == 2), beta = pop_bool, then 64 share words
+    (test/test_securenn.cpp:158-176)."""
+    w = prg_pops(seed, 0, 67 * n).reshape(n, 67)
+    x = w[:, 0].copy()
+    r = w[:, 1].copy()
+    if r_minus1_every5:
+        r[2::5] = -1
+    beta = (w[:, 2].view(np.uint64) % 2).astype(np.int8)
+    s0 = ((w[:, 3:].view(np.uint64) & 0xFFFF) % 67).astype(np.uint16)
+    bits = ((x.view(np.uint64)[:, None] >> np.arange(64, dtype=np.uint64)) & 1).astype(np.uint16)
+    s1 = ((bits + 67 - s0) % 67).astype(np.uint16)
+    return x, r, beta, np.ascontiguousarray(s0).ravel(), np.ascontiguousarray(s1).ravel()
+
+
+def test_snn_private_compare_property(orc):
+    n = 500
+    x, r, beta, s0, s1 = _pc_inputs(n)
+    w = pr.World(orc)
+    b2 = pr.snn_private_compare(w, [s0, s1], beta, r)
+    expect = (x.view(np.uint64) > r.view(np.uint64)).astype(np.int8)
+    assert np.array_equal(beta ^ b2, expect)  # test/test_securenn.cpp:185-189
+
+
+def test_snn_msb_1000_known_answer(orc):
+    """SecureNN msb at n = 1000 on a = pop/2 drawn from PRgenerator(22,0) after the 1000-element
+    privateCompare input draw; B_j share checksums recorded from the compiled reference."""
+    n = 1000
+    a = prg_pops(22, 67 * n, n)
+    a = (a // 2 + ((a < 0) & (a % 2 != 0))).astype(np.int64)  # C++ int64 division truncates toward zero
+    w = pr.World(orc)
+    As = pr.snn_share(w, a, n)
+    Bs = pr.snn_msb(w, As[:2])
+    B = pr.snn_reveal(w, Bs)
+    assert np.array_equal(B, (a < 0).astype(np.int64))  # test/test_securenn.cpp:302-305
+    assert [f"{fnv1a64(Bs[j]):016X}" for j in range(2)] == GOLD["snn_msb_1000"]["B_share"]
+
+
+def test_snn_share_convert_and_msb_l1_corners(orc):
+    """test/test_securenn.cpp:217-279: A == reveal_L_1(shareConvert(A)), msb_L_1 == (Y < 0), corner values."""
+    n = 10
+    A = prg_pops(KEY01, 1000, n)
+    A[A == -1] = 1
+    A[0], A[1], A[2], A[3] = 0, -2 ** 63, -2, 1
+    A[4] = np.int64(2 ** 63 - 1)  # (-2^63) - 1 wraps
+    w = pr.World(orc)
+    As = pr.snn_share(w, A, n)
+    Ys = pr.snn_share_convert(w, As[:2])
+    Y = orc.snn_add_L1(Ys[0], Ys[1])
+    assert np.array_equal(Y, A)
+    Bs = pr.snn_msb_L1(w, Ys)
+    assert np.array_equal(pr.snn_reveal(w, Bs), (Y < 0).astype(np.int64))
+
+
+def test_snn_vecmul_property(orc):
+    n = 5
+    rng = np.random.default_rng(3)
+    Xs = [rng.integers(-2 ** 63, 2 ** 63, n, dtype=np.int64) for _ in range(2)]
+    Ys = [rng.integers(-2 ** 63, 2 ** 63, n, dtype=np.int64) for _ in range(2)]
+    w = pr.World(orc)
+    Z = pr.snn_reveal(w, pr.snn_vecmul(w, Xs, Ys))
+    X, Y = orc.ring_add(Xs[0], Xs[1]), orc.ring_add(Ys[0], Ys[1])
+    assert np.array_equal(Z.view(np.uint64), X.view(np.uint64) * Y.view(np.uint64))
+
+
+def test_aby3_share_reveal_identity(orc):
+    n = 10  # test/test_ABY3.cpp:11-92
+    X = prg_pops(20, 0, n)
+    w = pr.World(orc)
+    for Z in pr.aby3_reveal(w, pr.aby3_share(w, X, n)):
+        assert np.array_equal(Z, X)
+    Xb = (X & 1).astype(np.int8)
+    for Z in pr.aby3_reveal_bools(w, pr.aby3_share_bools(w, Xb, n)):
+        assert np.array_equal(Z, Xb)
+
+
+def test_aby3_relu_chain_properties(orc):
+    """add_prepare + msb == (x < 0); bit_inject == x * msb (test/test_ABY3.cpp:184-223), incl. corners."""
+    n = 200
+    X = prg_pops(21, 0, n)
+    X[:6] = [0, -1, 1, -2 ** 63, 2 ** 63 - 1, -2]
+    w = pr.World(orc)
+    Xs = pr.aby3_share(w, X, n)
+    Gs, Ps = pr.aby3_add_prepare(w, Xs)
+    Zb = pr.aby3_msb(w, Gs, Ps)
+    for j in range(3):
+        assert np.array_equal(Zb[j][1], Zb[(j + 1) % 3][0])  # replicated sharing stays consistent
+    msb = pr.aby3_reveal_bools(w, Zb)
+    assert np.array_equal(msb[0], (X < 0).astype(np.int8))
+    C = pr.aby3_bit_inject(w, Xs, Zb)
+    for j in range(3):
+        assert np.array_equal(C[j][1], C[(j + 1) % 3][0])
+    prod = pr.aby3_reveal(w, C)
+    assert np.array_equal(prod[0], X * (X < 0))
+    # ReLU(x) = x - x*[x<0]
+    relu = orc.ring_sub(X, prod[0])
+    assert np.array_equal(relu, np.maximum(X, 0))
+
+
+def test_aby3_trunc_property(orc):
+    n = 50  # test/test_ABY3.cpp:227-254: within -1 of x >> 16 for 32-bit-range inputs
+    X = (prg_pops(23, 0, n) >> 32).astype(np.int64)
+    w = pr.World(orc)
+    Y = pr.aby3_reveal(w, pr.aby3_trunc(w, pr.aby3_share(w, X, n), 16))[0]
+    diff = Y - (X >> 16)
+    assert np.all((diff >= -1) & (diff <= 1))
+
+
+def test_aby3_vecmul_property(orc):
+    n = 10
+    X, Y = prg_pops(20, 0, n), prg_pops(20, n, n)
+    w = pr.World(orc)
+    Z = pr.aby3_reveal(w, pr.aby3_vecmul(w, pr.aby3_share(w, X, n), pr.aby3_share(w, Y, n), n))[0]
+    assert np.array_equal(Z.view(np.uint64), X.view(np.uint64) * Y.view(np.uint64))
