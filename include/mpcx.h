@@ -1,0 +1,210 @@
+/* mpcx -- C ABI of the MI355X (gfx950) implementation of the per-party local arithmetic of
+ * victerying/mpc's ABY3Engine and SecurennEngine.
+ *
+ * The reference has no FFI: its boundary is the C++ engine classes
+ * (mpc_engine/ABY3Engine.hpp:24-54, mpc_engine/SecurennEngine.hpp:20-50) whose methods all have the
+ * shape  local arithmetic -> VirtuleMessenger::send_and_recv -> local arithmetic.  This header exports
+ * ONE entry point per local-arithmetic segment between two messenger rounds.  Every message buffer
+ * uses exactly the reference's wire layout (utils/util.hpp:19-105,135-154,184-200: little-endian
+ * 64-bit words, matrices row-major, Z_67 bit shares as 64 uint16 per element LSB first, booleans one
+ * byte each), so a host engine built on these calls interoperates with reference peers.
+ *
+ * Conventions
+ *  - every data pointer is a DEVICE pointer (hipMalloc / mpcx_malloc / a torch tensor's data_ptr),
+ *    8-byte aligned unless it holds bytes; sizes and indices are uint64_t element counts;
+ *  - calls are asynchronous on the context's HIP stream (mpcx_set_stream / mpcx_sync);
+ *  - return value: 0 = ok, non-zero = error (text from mpcx_last_error); shapes are validated on the
+ *    host before any kernel is launched;
+ *  - one context per engine / host thread; a context is not thread-safe;
+ *  - PRG streams are named by the PRgenerator seed (lcg is 0 in both engines,
+ *    mpc_engine/ABY3Engine.cpp:34-53).  "pop index" k = the k-th pop_int64()/pop_bool() after
+ *    construction (utils/PRgenerator.cpp:34-42); "buffer index" i = int_buff[i] / bool_buff[i]
+ *    (utils/PRgenerator.cpp:27-32), defined for every i >= 0 by the same recurrence (the reference only
+ *    stores i < BUFF_NUM = 160000, utils/PRgenerator.hpp:6);
+ *  - (n_total, i0, n): the call handles elements [i0, i0+n) of a logical vector of n_total elements
+ *    (buffer offsets in SecurennEngine depend on the whole vector's size), which is how element
+ *    ranges are sharded over GPUs;
+ *  - layout flags: 0 = row-major, 1 = column-major (how Eigen stores MatrixXl).
+ */
+#ifndef MPCX_H
+#define MPCX_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mpcx_ctx mpcx_ctx;
+
+/* ---- context, memory, errors (no reference counterpart: the reference is host-only) ---- */
+int mpcx_init(int device, mpcx_ctx **out);
+int mpcx_shutdown(mpcx_ctx *ctx);
+const char *mpcx_last_error(mpcx_ctx *ctx); /* ctx may be NULL: error of a failed mpcx_init */
+int mpcx_set_stream(mpcx_ctx *ctx, void *hip_stream);
+void *mpcx_get_stream(mpcx_ctx *ctx);
+int mpcx_sync(mpcx_ctx *ctx);
+int mpcx_malloc(mpcx_ctx *ctx, uint64_t bytes, void **out);
+int mpcx_free(mpcx_ctx *ctx, void *p);
+int mpcx_h2d(mpcx_ctx *ctx, void *dst, const void *src, uint64_t bytes);
+int mpcx_d2h(mpcx_ctx *ctx, void *dst, const void *src, uint64_t bytes);
+int mpcx_d2d(mpcx_ctx *ctx, void *dst, const void *src, uint64_t bytes);
+/* grows the context's scratch workspace up front so that later calls do not allocate */
+int mpcx_reserve_workspace(mpcx_ctx *ctx, uint64_t bytes);
+
+/* ---- PRgenerator (utils/PRgenerator.cpp:3-42) ---- */
+/* Walks the stream on the host once and keeps a checkpoint every 256 outputs on host and device, so
+ * that kernels can regenerate any range in parallel.  n_pops / n_buff: how far the pop stream / the
+ * buffers will be read.  Called implicitly (and lazily) by everything below. */
+int mpcx_prg_ckpt_build(mpcx_ctx *ctx, uint64_t seed, uint64_t lcg, uint64_t n_pops, uint64_t n_buff);
+/* int_buff[first .. first+count) -> ints (nullable), bool_buff[...] -> bools (nullable)   (:27-32) */
+int mpcx_prg_fill_buff(mpcx_ctx *ctx, uint64_t seed, uint64_t lcg, uint64_t first, uint64_t count, int64_t *ints,
+                       int8_t *bools);
+/* pops first_pop .. first_pop+count of pop_int64()                                         (:34-37) */
+int mpcx_prg_fill_pop(mpcx_ctx *ctx, uint64_t seed, uint64_t lcg, uint64_t first_pop, uint64_t count, int64_t *out);
+/* host-side: the (seed, lcg, hash) members of a generator that has popped pop_index words  (:12-14) */
+int mpcx_prg_state_at_pop(mpcx_ctx *ctx, uint64_t seed, uint64_t lcg, uint64_t pop_index, uint64_t state_out[3]);
+
+/* ---- Z_2^64 helpers (Eigen int64 operator+,-,* as the engines use them) ---- */
+/* C (+)= A*B mod 2^64 on int8-limb MFMA; A is r x l, B is l x c */
+int mpcx_ring_gemm_u64(mpcx_ctx *ctx, const int64_t *A, const int64_t *B, int64_t *C, uint64_t r, uint64_t l,
+                       uint64_t c, int layoutA, int layoutB, int layoutC, int accumulate);
+int mpcx_ring_add(mpcx_ctx *ctx, const int64_t *a, const int64_t *b, int64_t *out, uint64_t n);
+int mpcx_ring_sub(mpcx_ctx *ctx, const int64_t *a, const int64_t *b, int64_t *out, uint64_t n);
+int mpcx_ring_sar(mpcx_ctx *ctx, const int64_t *a, int64_t *out, uint64_t n, int k); /* benchmark/benchmark1.cpp:106-112 */
+int mpcx_ring_shl1(mpcx_ctx *ctx, const int64_t *a, int64_t *out, uint64_t n);       /* SecurennEngine.cpp:1094-1098 */
+int mpcx_relayout(mpcx_ctx *ctx, const int64_t *src, int64_t *dst, uint64_t rows, uint64_t cols, int lay_src,
+                  int lay_dst);
+
+/* ---- ABY3Engine (mpc_engine/ABY3Engine.cpp) ---- */
+/* share / share_matrix before the round (:63-78, :83-103): out[i] = pop(next) - pop(prev) (+ X[i] when
+ * X != NULL, i.e. on party 0), i in row-major order */
+int mpcx_aby3_share_local(mpcx_ctx *ctx, const int64_t *X, uint64_t n, uint64_t seed_next, uint64_t pop_next,
+                          uint64_t seed_prev, uint64_t pop_prev, int64_t *out);
+/* share_bools before the round (:108-124) */
+int mpcx_aby3_share_bools_local(mpcx_ctx *ctx, const int8_t *X, uint64_t n, uint64_t seed_next, uint64_t pop_next,
+                                uint64_t seed_prev, uint64_t pop_prev, int8_t *out);
+/* matrix_mul before the round (:189-199): Z0 = X0*Y0 + X0*Y1 + X1*Y0 + (pop(next) - pop(prev)), inputs in
+ * `layout`, Z0 row-major (= matrix2string's order) */
+int mpcx_aby3_matmul_local(mpcx_ctx *ctx, const int64_t *X0, const int64_t *X1, const int64_t *Y0, const int64_t *Y1,
+                           uint64_t r, uint64_t l, uint64_t c, int layout, uint64_t seed_next, uint64_t pop_next,
+                           uint64_t seed_prev, uint64_t pop_prev, int64_t *Z0);
+/* row-block form for sharding over GPUs: rows [row0, row0+rows) of the r x l operands; X0/X1 point at the
+ * block (rows x l, row-major), Z0 receives rows x c; the mask uses pops pop_* + row0*c ... */
+int mpcx_aby3_matmul_local_rows(mpcx_ctx *ctx, const int64_t *X0blk, const int64_t *X1blk, const int64_t *Y0,
+                                const int64_t *Y1, uint64_t rows, uint64_t l, uint64_t c, uint64_t row0,
+                                uint64_t seed_next, uint64_t pop_next, uint64_t seed_prev, uint64_t pop_prev,
+                                int64_t *Z0blk);
+/* vector_mul before the round (:220-227) */
+int mpcx_aby3_vecmul_local(mpcx_ctx *ctx, const int64_t *X0, const int64_t *X1, const int64_t *Y0, const int64_t *Y1,
+                           uint64_t n, uint64_t seed_next, uint64_t pop_next, uint64_t seed_prev, uint64_t pop_prev,
+                           int64_t *Z0);
+/* reveal / reveal_matrix after the round (:142, :157): out = a + b + c ; reveal_bools (:171-174) and
+ * reveal_bits (:287-288): out = a ^ b ^ c */
+int mpcx_aby3_reveal3(mpcx_ctx *ctx, const int64_t *a, const int64_t *b, const int64_t *c, int64_t *out, uint64_t n);
+int mpcx_aby3_reveal3_bools(mpcx_ctx *ctx, const int8_t *a, const int8_t *b, const int8_t *c, int8_t *out, uint64_t n);
+int mpcx_aby3_reveal3_bits(mpcx_ctx *ctx, const int64_t *a, const int64_t *b, const int64_t *c, int64_t *out,
+                           uint64_t n);
+/* add_prepare (:295-326): step1 before round 1 (C0 = X0 & X1); step2 between the rounds */
+int mpcx_aby3_add_prepare_step1(mpcx_ctx *ctx, const int64_t *X0, const int64_t *X1, uint64_t n, int64_t *C0);
+int mpcx_aby3_add_prepare_step2(mpcx_ctx *ctx, const int64_t *X0, const int64_t *X1, const int64_t *C0,
+                                const int64_t *C1, uint64_t n, int64_t *P0, int64_t *P1, int64_t *G0);
+/* msb (:361-467), six rounds temp = 32,16,8,4,2,1.  The carry tree is kept as packed 64-bit words
+ * (bit b of word k = the reference's byte k*64+b); `state` is 4*n words {G0,G1,P0,P1}.
+ *  begin:      copies the inputs into state and applies :385-387 (G[63]=0, P[63]=1)
+ *  round_pre:  builds this round's vecbool_mul product share (:397-414, :253-256), writes it to msg_out
+ *              (2*temp bytes per element, the byte order of result[0]) and advances share 0 of the state
+ *  round_post: msg_in = result[1] received from next; advances share 1 of the state (:416-428)
+ *  final:      Z_i = G_i ^ backup_i (:459-466); P0_in/P1_in are the msb() inputs (bit 63 = backup) */
+int mpcx_aby3_msb_begin(mpcx_ctx *ctx, const int64_t *G0, const int64_t *G1, const int64_t *P0, const int64_t *P1,
+                        uint64_t n, uint64_t *state);
+int mpcx_aby3_msb_round_pre(mpcx_ctx *ctx, uint64_t *state, uint64_t n, uint64_t temp, int8_t *msg_out);
+int mpcx_aby3_msb_round_post(mpcx_ctx *ctx, uint64_t *state, uint64_t n, uint64_t temp, const int8_t *msg_in);
+int mpcx_aby3_msb_final(mpcx_ctx *ctx, const uint64_t *state, const int64_t *P0_in, const int64_t *P1_in, uint64_t n,
+                        int8_t *Z0, int8_t *Z1);
+/* trunc before the round (:480-503); seed12/pop12 = the stream parties 1 and 2 share */
+int mpcx_aby3_trunc_local(mpcx_ctx *ctx, int party, const int64_t *X0, const int64_t *X1, uint64_t n, int number,
+                          uint64_t seed12, uint64_t pop12, int64_t *Y0);
+/* bit_inject (:510-1038), one pre (before the round) and one post (after) per party.  Message layouts:
+ *  P0: to_p1 = (M0_0^W02_0)[n]|(M0_1^W02_1)[n]            to_p2 = (M0_0^W01_0)[n]|(M0_1^W01_1)[n]|W10_b[n]
+ *  P1: to_p0 = (M1_0^W12_0)[n]|(M1_1^W12_1)[n]            to_p2 = W01_b[n]|(M1_0^W10_0)[n]|(M1_1^W10_1)[n]
+ *  P2: to_p0 = W12_b[n]                                   to_p1 = W02_b[n]
+ * pop01/pop20/pop12 = the caller's pop index into that stream when bit_inject starts (the call consumes
+ * 6n words of s01 and 3n of s20 on P0; 6n of s01, 3n of s12 on P1; 3n of s20, 3n of s12 on P2). */
+int mpcx_aby3_bit_inject_p0_pre(mpcx_ctx *ctx, const int64_t *A0, const int8_t *B0, const int8_t *B1, uint64_t n,
+                                uint64_t seed01, uint64_t pop01, uint64_t seed20, uint64_t pop20, int64_t *to_p1,
+                                int64_t *to_p2);
+int mpcx_aby3_bit_inject_p0_post(mpcx_ctx *ctx, const int8_t *B0, uint64_t n, uint64_t seed01, uint64_t pop01,
+                                 uint64_t seed20, uint64_t pop20, const int64_t *from_p1, const int64_t *from_p2,
+                                 int64_t *C0, int64_t *C1);
+int mpcx_aby3_bit_inject_p1_pre(mpcx_ctx *ctx, const int64_t *A0, const int64_t *A1, const int8_t *B0,
+                                const int8_t *B1, uint64_t n, uint64_t seed01, uint64_t pop01, uint64_t seed12,
+                                uint64_t pop12, int64_t *to_p0, int64_t *to_p2);
+int mpcx_aby3_bit_inject_p1_post(mpcx_ctx *ctx, const int8_t *B1, uint64_t n, uint64_t seed01, uint64_t pop01,
+                                 uint64_t seed12, uint64_t pop12, const int64_t *from_p0, const int64_t *from_p2,
+                                 int64_t *C0, int64_t *C1);
+int mpcx_aby3_bit_inject_p2_pre(mpcx_ctx *ctx, const int8_t *B0, const int8_t *B1, uint64_t n, uint64_t seed20,
+                                uint64_t pop20, uint64_t seed12, uint64_t pop12, int64_t *to_p0, int64_t *to_p1);
+int mpcx_aby3_bit_inject_p2_post(mpcx_ctx *ctx, const int8_t *B0, const int8_t *B1, uint64_t n, uint64_t seed20,
+                                 uint64_t pop20, uint64_t seed12, uint64_t pop12, const int64_t *from_p0,
+                                 const int64_t *from_p1, int64_t *C0, int64_t *C1);
+
+/* ---- SecurennEngine (mpc_engine/SecurennEngine.cpp) ---- */
+/* share (:318-334): party 0: -pop(s01); party 1: X + pop(s01); party 2: zeros */
+int mpcx_snn_share_local(mpcx_ctx *ctx, int party, const int64_t *X, uint64_t n, uint64_t seed01, uint64_t pop01,
+                         int64_t *out);
+/* reveal_L_1 (:448,:459) and reveal_zp (:482,:496) combine steps */
+int mpcx_snn_add_L1(mpcx_ctx *ctx, const int64_t *a, const int64_t *b, int64_t *out, uint64_t n);
+int mpcx_snn_add_zp(mpcx_ctx *ctx, const uint16_t *a, const uint16_t *b, uint16_t *out, uint64_t n64);
+/* matrix_mul (:61-169).  dealer = party 2 before round 1: msg_i = A_i|B_i|C_i (row-major) from the self
+ * stream's buffer; open = party 0/1 between the rounds: ef = (X-A)|(Y-B); finish = after round 2:
+ * Z = C + E*B + A*F + party*E*F, written in layoutZ */
+int mpcx_snn_beaver_dealer_matmul(mpcx_ctx *ctx, uint64_t seedS, uint64_t r, uint64_t l, uint64_t c, int64_t *msg0,
+                                  int64_t *msg1);
+int mpcx_snn_beaver_party_open_matmul(mpcx_ctx *ctx, const int64_t *X, const int64_t *Y, int layout,
+                                      const int64_t *triple, uint64_t r, uint64_t l, uint64_t c, int64_t *ef_out);
+int mpcx_snn_beaver_party_finish_matmul(mpcx_ctx *ctx, int party, const int64_t *triple, const int64_t *ef_own,
+                                        const int64_t *ef_peer, uint64_t r, uint64_t l, uint64_t c, int layoutZ,
+                                        int64_t *Z);
+/* vector_mul (:171-316) */
+int mpcx_snn_beaver_dealer_vecmul(mpcx_ctx *ctx, uint64_t seedS, uint64_t n_total, uint64_t i0, uint64_t n,
+                                  int64_t *A0, int64_t *B0, int64_t *C0, int64_t *A1, int64_t *B1, int64_t *C1);
+int mpcx_snn_beaver_party_open_vecmul(mpcx_ctx *ctx, const int64_t *X, const int64_t *Y, const int64_t *A,
+                                      const int64_t *B, uint64_t n, int64_t *E, int64_t *F);
+int mpcx_snn_beaver_party_finish_vecmul(mpcx_ctx *ctx, int party, const int64_t *A, const int64_t *B,
+                                        const int64_t *C, const int64_t *E_own, const int64_t *F_own,
+                                        const int64_t *E_peer, const int64_t *F_peer, uint64_t n, int64_t *Z);
+/* privateCompare (:507-680).  party (0/1): d = s * c over Z_67 with s,u regenerated on the device from the
+ * s01 buffer (:523-534); helper (party 2): beta'[i] = any_k((d0+d1)[i][k] % 67 == 0) (:655-669) */
+int mpcx_snn_pc_party(mpcx_ctx *ctx, int party, const uint16_t *xbits, const int8_t *beta, const int64_t *r,
+                      uint64_t n_total, uint64_t i0, uint64_t n, uint64_t seed01, uint16_t *d_out);
+int mpcx_snn_pc_helper(mpcx_ctx *ctx, const uint16_t *d0, const uint16_t *d1, uint64_t n, int8_t *beta_out);
+/* shareConvert (:685-893) */
+int mpcx_snn_sc_party_open(mpcx_ctx *ctx, int party, const int64_t *A, uint64_t n_total, uint64_t i0, uint64_t n,
+                           uint64_t seed01, int64_t *x_out);
+int mpcx_snn_sc_party_pc_inputs(mpcx_ctx *ctx, uint64_t n_total, uint64_t i0, uint64_t n, uint64_t seed01,
+                                int8_t *eta2_out, int64_t *rm1_out);
+int mpcx_snn_sc_party_finish(mpcx_ctx *ctx, int party, const int64_t *A, const int64_t *delta_j,
+                             const int64_t *eta1_j, uint64_t n_total, uint64_t i0, uint64_t n, uint64_t seed01,
+                             int64_t *y_out);
+int mpcx_snn_sc_helper_split(mpcx_ctx *ctx, const int64_t *x0, const int64_t *x1, uint64_t n_total, uint64_t i0,
+                             uint64_t n, uint64_t seedS, uint16_t *xbits0, int64_t *delta0, uint16_t *xbits1,
+                             int64_t *delta1);
+int mpcx_snn_sc_helper_eta(mpcx_ctx *ctx, const int8_t *eta1_plain, uint64_t n_total, uint64_t i0, uint64_t n,
+                           uint64_t seedS, int64_t *eta0, int64_t *eta1);
+/* msb_L_1 (:898-1084) */
+int mpcx_snn_msbl1_helper_deal(mpcx_ctx *ctx, uint64_t n_total, uint64_t i0, uint64_t n, uint64_t seedS, int64_t *x0,
+                               int64_t *xlsb0, uint16_t *xbits0, int64_t *x1, int64_t *xlsb1, uint16_t *xbits1);
+int mpcx_snn_msbl1_helper_beta(mpcx_ctx *ctx, const int8_t *beta1_plain, uint64_t n_total, uint64_t i0, uint64_t n,
+                               uint64_t seedS, int64_t *b0, int64_t *b1);
+int mpcx_snn_msbl1_party_open(mpcx_ctx *ctx, const int64_t *A, const int64_t *xj, uint64_t n, int64_t *r_out);
+int mpcx_snn_msbl1_party_pc_inputs(mpcx_ctx *ctx, const int64_t *r_own, const int64_t *r_peer, uint64_t i0,
+                                   uint64_t n, uint64_t seed01, int8_t *beta_out, int64_t *R_out);
+int mpcx_snn_msbl1_party_mid(mpcx_ctx *ctx, int party, const int64_t *beta1_j, const int64_t *xlsb_j,
+                             const int8_t *beta0, const int64_t *R, uint64_t n, int64_t *gamma_out,
+                             int64_t *delta_out);
+int mpcx_snn_msbl1_party_finish(mpcx_ctx *ctx, const int64_t *gamma, const int64_t *delta, const int64_t *theta,
+                                uint64_t n, int64_t *B);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPCX_H */

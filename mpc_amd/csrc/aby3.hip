@@ -1,0 +1,476 @@
+// Per-party local segments of ABY3Engine (mpc_engine/ABY3Engine.cpp) as HIP kernels.
+// All kernels are streaming, HBM-bound passes over 64-bit share words; the carry tree of msb() is
+// kept as packed 64-bit words and only the wire messages are expanded to one byte per bit.
+#include "mpcx_internal.h"
+
+namespace {
+
+template <class F> __global__ __launch_bounds__(256) void ew_kernel(u64 n, F f) {
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256) f(i);
+}
+template <class F> int ew_launch(mpcx_ctx *ctx, u64 n, F f) {
+    if (n == 0) return 0;
+    u64 blocks = ceil_div(n, 256);
+    if (blocks > 256 * 16) blocks = 256 * 16; // 16 workgroups per CU, grid-stride the rest
+    hipLaunchKernelGGL(ew_kernel<F>, dim3((u32)blocks), dim3(256), 0, ctx->stream, n, f);
+    MPCX_LAUNCH_CHECK();
+    return 0;
+}
+
+// mask of the carry-tree positions that are still live when pairs are `s` bits apart:
+// bits at multiples of 2s
+__device__ inline u64 even_mask(u32 s) {
+    switch (s) {
+    case 1: return 0x5555555555555555ull;
+    case 2: return 0x1111111111111111ull;
+    case 4: return 0x0101010101010101ull;
+    case 8: return 0x0001000100010001ull;
+    case 16: return 0x0000000100000001ull;
+    default: return 1ull;
+    }
+}
+// this round's product share of the element (ABY3Engine.cpp:397-414 + :253-256) on packed words:
+// even result bits pair (P[2m+1], G[2m]), odd result bits pair (P[2m+1], P[2m]); bit m sits at 2*m*s.
+__device__ inline void msb_products(u64 g0, u64 g1, u64 p0, u64 p1, u32 s, u64 &re, u64 &ro) {
+    const u64 E = even_mask(s);
+    const u64 po0 = (p0 >> s) & E, po1 = (p1 >> s) & E;
+    const u64 ge0 = g0 & E, ge1 = g1 & E, pe0 = p0 & E, pe1 = p1 & E;
+    re = (po0 & ge0) ^ (po1 & ge0) ^ (po0 & ge1);
+    ro = (po0 & pe0) ^ (po1 & pe0) ^ (po0 & pe1);
+}
+// 8 wire bytes: pairs m = m0..m0+3 -> byte 2j = even bit, byte 2j+1 = odd bit
+__device__ inline u64 msb_pack8(u64 re, u64 ro, u32 m0, u32 s, u32 npairs) {
+    u64 w = 0;
+#pragma unroll
+    for (u32 j = 0; j < 4; j++) {
+        if (j < npairs) {
+            const u32 pos = 2 * (m0 + j) * s;
+            w |= ((re >> pos) & 1ull) << (16 * j);
+            w |= ((ro >> pos) & 1ull) << (16 * j + 8);
+        }
+    }
+    return w;
+}
+__device__ inline void msb_unpack8(u64 w, u32 m0, u32 s, u32 npairs, u64 &re, u64 &ro) {
+#pragma unroll
+    for (u32 j = 0; j < 4; j++) {
+        if (j < npairs) {
+            const u32 pos = 2 * (m0 + j) * s;
+            re |= ((w >> (16 * j)) & 1ull) << pos;
+            ro |= ((w >> (16 * j + 8)) & 1ull) << pos;
+        }
+    }
+}
+
+// temp >= 4: temp/4 lanes per element, each writes one 8-byte piece of the element's 2*temp bytes
+__global__ __launch_bounds__(256) void msb_round_pre_wide(u64 *__restrict__ st, u64 n, u32 temp, u64 *__restrict__ msg) {
+    const u32 s = 32 / temp, g = temp / 4;
+    const u64 chunks = n * g;
+    for (u64 c = (u64)blockIdx.x * 256 + threadIdx.x; c < chunks; c += (u64)gridDim.x * 256) {
+        const u64 k = c / g;
+        const u32 q = (u32)(c - k * g);
+        const u64 g0 = st[k], g1 = st[n + k], p0 = st[2 * n + k], p1 = st[3 * n + k];
+        u64 re, ro;
+        msb_products(g0, g1, p0, p1, s, re, ro);
+        msg[c] = msb_pack8(re, ro, 4 * q, s, 4);
+        if (q == 0) { // advance share 0 (:424-425): G' = res_even ^ G_odd, P' = res_odd
+            st[k] = re ^ ((g0 >> s) & even_mask(s));
+            st[2 * n + k] = ro;
+        }
+    }
+}
+// temp in {1,2}: one lane per element, 2*temp bytes each
+__global__ __launch_bounds__(256) void msb_round_pre_narrow(u64 *__restrict__ st, u64 n, u32 temp, u8 *__restrict__ msg) {
+    const u32 s = 32 / temp;
+    for (u64 k = (u64)blockIdx.x * 256 + threadIdx.x; k < n; k += (u64)gridDim.x * 256) {
+        const u64 g0 = st[k], g1 = st[n + k], p0 = st[2 * n + k], p1 = st[3 * n + k];
+        u64 re, ro;
+        msb_products(g0, g1, p0, p1, s, re, ro);
+        const u64 w = msb_pack8(re, ro, 0, s, temp);
+        if (temp == 2)
+            *(u32 *)(msg + 4 * k) = (u32)w;
+        else
+            *(u16 *)(msg + 2 * k) = (u16)w;
+        st[k] = re ^ ((g0 >> s) & even_mask(s));
+        st[2 * n + k] = ro;
+    }
+}
+// share 1 after the round (:416-428 with i = 1): the temp/4 lanes of an element OR their pieces together
+__global__ __launch_bounds__(256) void msb_round_post_wide(u64 *__restrict__ st, u64 n, u32 temp,
+                                                           const u64 *__restrict__ msg) {
+    const u32 s = 32 / temp, g = temp / 4;
+    const u64 chunks = n * g;
+    // every lane of a group must reach the shuffles: iterate on a group-aligned, wave-uniform trip count
+    const u64 stride = (u64)gridDim.x * 256;
+    for (u64 base = (u64)blockIdx.x * 256; base < chunks; base += stride) {
+        const u64 c = base + threadIdx.x;
+        const bool live = c < chunks;
+        const u64 k = live ? c / g : 0;
+        const u32 q = live ? (u32)(c - k * g) : 0;
+        u64 re = 0, ro = 0;
+        if (live) msb_unpack8(msg[c], 4 * q, s, 4, re, ro);
+        for (u32 d = 1; d < g; d <<= 1) { // groups are aligned runs of g lanes (g divides 64 and 256)
+            re |= __shfl_xor(re, d);
+            ro |= __shfl_xor(ro, d);
+        }
+        if (live && q == 0) {
+            const u64 g1 = st[n + k];
+            st[n + k] = re ^ ((g1 >> s) & even_mask(s));
+            st[3 * n + k] = ro;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void msb_round_post_narrow(u64 *__restrict__ st, u64 n, u32 temp,
+                                                             const u8 *__restrict__ msg) {
+    const u32 s = 32 / temp;
+    for (u64 k = (u64)blockIdx.x * 256 + threadIdx.x; k < n; k += (u64)gridDim.x * 256) {
+        const u64 w = (temp == 2) ? (u64) * (const u32 *)(msg + 4 * k) : (u64) * (const u16 *)(msg + 2 * k);
+        u64 re = 0, ro = 0;
+        msb_unpack8(w, 0, s, temp, re, ro);
+        const u64 g1 = st[n + k];
+        st[n + k] = re ^ ((g1 >> s) & even_mask(s));
+        st[3 * n + k] = ro;
+    }
+}
+
+inline u32 grid_for(u64 work) {
+    u64 b = ceil_div(work, 256);
+    if (b > 4096) b = 4096;
+    if (b == 0) b = 1;
+    return (u32)b;
+}
+
+} // namespace
+
+extern "C" {
+
+int mpcx_ring_add(mpcx_ctx *ctx, const int64_t *a, const int64_t *b, int64_t *out, uint64_t n) {
+    MPCX_REQUIRE((a && b && out) || n == 0, "mpcx_ring_add: NULL pointer");
+    const u64 *x = (const u64 *)a, *y = (const u64 *)b;
+    u64 *o = (u64 *)out;
+    return ew_launch(ctx, n, [=] __device__(u64 i) { o[i] = x[i] + y[i]; });
+}
+int mpcx_ring_sub(mpcx_ctx *ctx, const int64_t *a, const int64_t *b, int64_t *out, uint64_t n) {
+    MPCX_REQUIRE((a && b && out) || n == 0, "mpcx_ring_sub: NULL pointer");
+    const u64 *x = (const u64 *)a, *y = (const u64 *)b;
+    u64 *o = (u64 *)out;
+    return ew_launch(ctx, n, [=] __device__(u64 i) { o[i] = x[i] - y[i]; });
+}
+int mpcx_ring_sar(mpcx_ctx *ctx, const int64_t *a, int64_t *out, uint64_t n, int k) {
+    MPCX_REQUIRE((a && out) || n == 0, "mpcx_ring_sar: NULL pointer");
+    MPCX_REQUIRE(k >= 0 && k < 64, "mpcx_ring_sar: shift %d out of range", k);
+    return ew_launch(ctx, n, [=] __device__(u64 i) { out[i] = a[i] >> k; });
+}
+int mpcx_ring_shl1(mpcx_ctx *ctx, const int64_t *a, int64_t *out, uint64_t n) {
+    MPCX_REQUIRE((a && out) || n == 0, "mpcx_ring_shl1: NULL pointer");
+    const u64 *x = (const u64 *)a;
+    u64 *o = (u64 *)out;
+    return ew_launch(ctx, n, [=] __device__(u64 i) { o[i] = x[i] << 1; });
+}
+
+int mpcx_aby3_share_local(mpcx_ctx *ctx, const int64_t *X, uint64_t n, uint64_t seed_next, uint64_t pop_next,
+                          uint64_t seed_prev, uint64_t pop_prev, int64_t *out) {
+    if (n == 0) return 0;
+    MPCX_REQUIRE(out, "mpcx_aby3_share_local: out is NULL");
+    void *ws;
+    MPCX_TRY(mpcx_ws(ctx, 16 * n, &ws));
+    u64 *a = (u64 *)ws, *b = a + n;
+    MPCX_TRY(prg_fill_words(ctx, seed_next, 0, PRG_POP_T0 + pop_next, n, 1, (i64 *)a, nullptr));
+    MPCX_TRY(prg_fill_words(ctx, seed_prev, 0, PRG_POP_T0 + pop_prev, n, 1, (i64 *)b, nullptr));
+    const u64 *x = (const u64 *)X;
+    u64 *o = (u64 *)out;
+    return ew_launch(ctx, n, [=] __device__(u64 i) {
+        u64 r = a[i] - b[i];
+        o[i] = x ? r + x[i] : r;
+    });
+}
+
+int mpcx_aby3_share_bools_local(mpcx_ctx *ctx, const int8_t *X, uint64_t n, uint64_t seed_next, uint64_t pop_next,
+                                uint64_t seed_prev, uint64_t pop_prev, int8_t *out) {
+    if (n == 0) return 0;
+    MPCX_REQUIRE(out, "mpcx_aby3_share_bools_local: out is NULL");
+    void *ws;
+    MPCX_TRY(mpcx_ws(ctx, 16 * n, &ws));
+    u64 *a = (u64 *)ws, *b = a + n;
+    MPCX_TRY(prg_fill_words(ctx, seed_next, 0, PRG_POP_T0 + pop_next, n, 1, (i64 *)a, nullptr));
+    MPCX_TRY(prg_fill_words(ctx, seed_prev, 0, PRG_POP_T0 + pop_prev, n, 1, (i64 *)b, nullptr));
+    return ew_launch(ctx, n, [=] __device__(u64 i) {
+        i8 r = (i8)((a[i] & 1) ^ (b[i] & 1));
+        out[i] = X ? (i8)(r ^ X[i]) : r;
+    });
+}
+
+// Z0 = X0*(Y0+Y1) + X1*Y0 = [X0 | X1] * [Y0+Y1 ; Y0]  (ABY3Engine.cpp:189) as ONE K-concatenated ring
+// product, with the mask pop(next) - pop(prev) (:190-197) fused into the recombination pass.
+static int aby3_matmul_impl(mpcx_ctx *ctx, const i64 *X0, const i64 *X1, const i64 *Y0, const i64 *Y1, u64 rows, u64 l,
+                            u64 c, int layout, u64 first_word, u64 seed_next, u64 pop_next, u64 seed_prev, u64 pop_prev,
+                            i64 *Z0) {
+    const u64 nz = rows * c;
+    const u64 gemm_bytes = ring_gemm_ws_bytes(2, rows, l, c);
+    void *ws;
+    MPCX_TRY(mpcx_ws(ctx, gemm_bytes + 16 * nz, &ws)); // the gemm driver takes the front, the mask words the tail
+    u64 *mask = (u64 *)((u8 *)ws + gemm_bytes);
+    MPCX_TRY(prg_fill_words(ctx, seed_next, 0, PRG_POP_T0 + pop_next + first_word, nz, 1, (i64 *)mask, nullptr));
+    MPCX_TRY(prg_fill_words(ctx, seed_prev, 0, PRG_POP_T0 + pop_prev + first_word, nz, 1, (i64 *)(mask + nz), nullptr));
+    GemmPart parts[2] = {{X0, Y0, Y1}, {X1, Y0, nullptr}};
+    return ring_gemm_parts(ctx, parts, 2, rows, l, c, layout, layout, (const i64 *)mask, (const i64 *)(mask + nz), Z0, 0, 0);
+}
+
+int mpcx_aby3_matmul_local_rows(mpcx_ctx *ctx, const int64_t *X0, const int64_t *X1, const int64_t *Y0,
+                                const int64_t *Y1, uint64_t rows, uint64_t l, uint64_t c, uint64_t row0,
+                                uint64_t seed_next, uint64_t pop_next, uint64_t seed_prev, uint64_t pop_prev,
+                                int64_t *Z0) {
+    MPCX_REQUIRE(X0 && X1 && Y0 && Y1 && Z0, "mpcx_aby3_matmul_local_rows: NULL operand");
+    MPCX_REQUIRE(rows && l && c, "mpcx_aby3_matmul_local_rows: empty shape");
+    return aby3_matmul_impl(ctx, X0, X1, Y0, Y1, rows, l, c, 0, row0 * c, seed_next, pop_next, seed_prev, pop_prev, Z0);
+}
+
+int mpcx_aby3_matmul_local(mpcx_ctx *ctx, const int64_t *X0, const int64_t *X1, const int64_t *Y0, const int64_t *Y1,
+                           uint64_t r, uint64_t l, uint64_t c, int layout, uint64_t seed_next, uint64_t pop_next,
+                           uint64_t seed_prev, uint64_t pop_prev, int64_t *Z0) {
+    MPCX_REQUIRE(X0 && X1 && Y0 && Y1 && Z0, "mpcx_aby3_matmul_local: NULL operand");
+    MPCX_REQUIRE(r && l && c, "mpcx_aby3_matmul_local: empty shape");
+    MPCX_REQUIRE(layout == 0 || layout == 1, "mpcx_aby3_matmul_local: layout must be 0 or 1");
+    return aby3_matmul_impl(ctx, X0, X1, Y0, Y1, r, l, c, layout, 0, seed_next, pop_next, seed_prev, pop_prev, Z0);
+}
+
+int mpcx_aby3_vecmul_local(mpcx_ctx *ctx, const int64_t *X0, const int64_t *X1, const int64_t *Y0, const int64_t *Y1,
+                           uint64_t n, uint64_t seed_next, uint64_t pop_next, uint64_t seed_prev, uint64_t pop_prev,
+                           int64_t *Z0) {
+    if (n == 0) return 0;
+    MPCX_REQUIRE(X0 && X1 && Y0 && Y1 && Z0, "mpcx_aby3_vecmul_local: NULL operand");
+    void *ws;
+    MPCX_TRY(mpcx_ws(ctx, 16 * n, &ws));
+    u64 *a = (u64 *)ws, *b = a + n;
+    MPCX_TRY(prg_fill_words(ctx, seed_next, 0, PRG_POP_T0 + pop_next, n, 1, (i64 *)a, nullptr));
+    MPCX_TRY(prg_fill_words(ctx, seed_prev, 0, PRG_POP_T0 + pop_prev, n, 1, (i64 *)b, nullptr));
+    const u64 *x0 = (const u64 *)X0, *x1 = (const u64 *)X1, *y0 = (const u64 *)Y0, *y1 = (const u64 *)Y1;
+    u64 *z = (u64 *)Z0;
+    return ew_launch(ctx, n, [=] __device__(u64 i) {
+        z[i] = x0[i] * y0[i] + x0[i] * y1[i] + x1[i] * y0[i] + (a[i] - b[i]);
+    });
+}
+
+int mpcx_aby3_reveal3(mpcx_ctx *ctx, const int64_t *a, const int64_t *b, const int64_t *c, int64_t *out, uint64_t n) {
+    MPCX_REQUIRE((a && b && c && out) || n == 0, "mpcx_aby3_reveal3: NULL pointer");
+    const u64 *x = (const u64 *)a, *y = (const u64 *)b, *z = (const u64 *)c;
+    u64 *o = (u64 *)out;
+    return ew_launch(ctx, n, [=] __device__(u64 i) { o[i] = x[i] + y[i] + z[i]; });
+}
+int mpcx_aby3_reveal3_bools(mpcx_ctx *ctx, const int8_t *a, const int8_t *b, const int8_t *c, int8_t *out, uint64_t n) {
+    MPCX_REQUIRE((a && b && c && out) || n == 0, "mpcx_aby3_reveal3_bools: NULL pointer");
+    return ew_launch(ctx, n, [=] __device__(u64 i) { out[i] = (i8)(a[i] ^ b[i] ^ c[i]); });
+}
+int mpcx_aby3_reveal3_bits(mpcx_ctx *ctx, const int64_t *a, const int64_t *b, const int64_t *c, int64_t *out,
+                           uint64_t n) {
+    MPCX_REQUIRE((a && b && c && out) || n == 0, "mpcx_aby3_reveal3_bits: NULL pointer");
+    return ew_launch(ctx, n, [=] __device__(u64 i) { out[i] = a[i] ^ b[i] ^ c[i]; });
+}
+
+int mpcx_aby3_add_prepare_step1(mpcx_ctx *ctx, const int64_t *X0, const int64_t *X1, uint64_t n, int64_t *C0) {
+    MPCX_REQUIRE((X0 && X1 && C0) || n == 0, "mpcx_aby3_add_prepare_step1: NULL pointer");
+    return ew_launch(ctx, n, [=] __device__(u64 i) { C0[i] = X0[i] & X1[i]; });
+}
+int mpcx_aby3_add_prepare_step2(mpcx_ctx *ctx, const int64_t *X0, const int64_t *X1, const int64_t *C0,
+                                const int64_t *C1, uint64_t n, int64_t *P0, int64_t *P1, int64_t *G0) {
+    MPCX_REQUIRE((X0 && X1 && C0 && C1 && P0 && P1 && G0) || n == 0, "mpcx_aby3_add_prepare_step2: NULL pointer");
+    return ew_launch(ctx, n, [=] __device__(u64 i) {
+        const u64 s0 = (u64)X0[i], s1 = (u64)X1[i];
+        const u64 c0 = (u64)C0[i] << 1, c1 = (u64)C1[i] << 1;
+        P0[i] = (i64)(c0 ^ s0);
+        P1[i] = (i64)(c1 ^ s1);
+        G0[i] = (i64)((c0 & s0) ^ (c0 & s1) ^ (c1 & s0));
+    });
+}
+
+int mpcx_aby3_msb_begin(mpcx_ctx *ctx, const int64_t *G0, const int64_t *G1, const int64_t *P0, const int64_t *P1,
+                        uint64_t n, uint64_t *state) {
+    MPCX_REQUIRE((G0 && G1 && P0 && P1 && state) || n == 0, "mpcx_aby3_msb_begin: NULL pointer");
+    const u64 top = 1ull << 63;
+    return ew_launch(ctx, n, [=] __device__(u64 i) {
+        state[i] = (u64)G0[i] & ~top; // ABY3Engine.cpp:386
+        state[n + i] = (u64)G1[i] & ~top;
+        state[2 * n + i] = (u64)P0[i] | top; // :387
+        state[3 * n + i] = (u64)P1[i] | top;
+    });
+}
+int mpcx_aby3_msb_round_pre(mpcx_ctx *ctx, uint64_t *state, uint64_t n, uint64_t temp, int8_t *msg_out) {
+    if (n == 0) return 0;
+    MPCX_REQUIRE(state && msg_out, "mpcx_aby3_msb_round_pre: NULL pointer");
+    MPCX_REQUIRE(temp == 32 || temp == 16 || temp == 8 || temp == 4 || temp == 2 || temp == 1,
+                 "mpcx_aby3_msb_round_pre: temp must be one of 32,16,8,4,2,1");
+    MPCX_REQUIRE(((uintptr_t)msg_out & 7) == 0, "mpcx_aby3_msb_round_pre: msg_out must be 8-byte aligned");
+    if (temp >= 4)
+        hipLaunchKernelGGL(msb_round_pre_wide, dim3(grid_for(n * (temp / 4))), dim3(256), 0, ctx->stream, state, n,
+                           (u32)temp, (u64 *)msg_out);
+    else
+        hipLaunchKernelGGL(msb_round_pre_narrow, dim3(grid_for(n)), dim3(256), 0, ctx->stream, state, n, (u32)temp,
+                           (u8 *)msg_out);
+    MPCX_LAUNCH_CHECK();
+    return 0;
+}
+int mpcx_aby3_msb_round_post(mpcx_ctx *ctx, uint64_t *state, uint64_t n, uint64_t temp, const int8_t *msg_in) {
+    if (n == 0) return 0;
+    MPCX_REQUIRE(state && msg_in, "mpcx_aby3_msb_round_post: NULL pointer");
+    MPCX_REQUIRE(temp == 32 || temp == 16 || temp == 8 || temp == 4 || temp == 2 || temp == 1,
+                 "mpcx_aby3_msb_round_post: temp must be one of 32,16,8,4,2,1");
+    MPCX_REQUIRE(((uintptr_t)msg_in & 7) == 0, "mpcx_aby3_msb_round_post: msg_in must be 8-byte aligned");
+    if (temp >= 4)
+        hipLaunchKernelGGL(msb_round_post_wide, dim3(grid_for(n * (temp / 4))), dim3(256), 0, ctx->stream, state, n,
+                           (u32)temp, (const u64 *)msg_in);
+    else
+        hipLaunchKernelGGL(msb_round_post_narrow, dim3(grid_for(n)), dim3(256), 0, ctx->stream, state, n, (u32)temp,
+                           (const u8 *)msg_in);
+    MPCX_LAUNCH_CHECK();
+    return 0;
+}
+int mpcx_aby3_msb_final(mpcx_ctx *ctx, const uint64_t *state, const int64_t *P0_in, const int64_t *P1_in, uint64_t n,
+                        int8_t *Z0, int8_t *Z1) {
+    MPCX_REQUIRE((state && P0_in && P1_in && Z0 && Z1) || n == 0, "mpcx_aby3_msb_final: NULL pointer");
+    return ew_launch(ctx, n, [=] __device__(u64 i) {
+        Z0[i] = (i8)((state[i] & 1) ^ ((u64)P0_in[i] >> 63));
+        Z1[i] = (i8)((state[n + i] & 1) ^ ((u64)P1_in[i] >> 63));
+    });
+}
+
+int mpcx_aby3_trunc_local(mpcx_ctx *ctx, int party, const int64_t *X0, const int64_t *X1, uint64_t n, int number,
+                          uint64_t seed12, uint64_t pop12, int64_t *Y0) {
+    if (n == 0) return 0;
+    MPCX_REQUIRE(party >= 0 && party <= 2, "mpcx_aby3_trunc_local: party %d", party);
+    MPCX_REQUIRE(number >= 0 && number < 64, "mpcx_aby3_trunc_local: shift %d out of range", number);
+    MPCX_REQUIRE(Y0 && (party == 2 || X0) && (party != 1 || X1), "mpcx_aby3_trunc_local: NULL pointer");
+    if (party == 0) return ew_launch(ctx, n, [=] __device__(u64 i) { Y0[i] = X0[i] >> number; });
+    if (party == 2) return prg_fill_words(ctx, seed12, 0, PRG_POP_T0 + pop12, n, 1, Y0, nullptr);
+    void *ws;
+    MPCX_TRY(mpcx_ws(ctx, 8 * n, &ws));
+    u64 *w = (u64 *)ws;
+    MPCX_TRY(prg_fill_words(ctx, seed12, 0, PRG_POP_T0 + pop12, n, 1, (i64 *)w, nullptr));
+    return ew_launch(ctx, n, [=] __device__(u64 i) {
+        i64 t = (i64)((u64)X0[i] + (u64)X1[i]);
+        t >>= number;
+        Y0[i] = (i64)((u64)t - w[i]);
+    });
+}
+
+// ---- bit_inject: the PRG words of the call are regenerated into scratch (s01: 6n or 3n words, other
+// stream: 3n words), then one streaming pass forms the messages / the output shares.
+int mpcx_aby3_bit_inject_p0_pre(mpcx_ctx *ctx, const int64_t *A0, const int8_t *B0, const int8_t *B1, uint64_t n,
+                                uint64_t seed01, uint64_t pop01, uint64_t seed20, uint64_t pop20, int64_t *to_p1,
+                                int64_t *to_p2) {
+    if (n == 0) return 0;
+    MPCX_REQUIRE(A0 && B0 && B1 && to_p1 && to_p2, "mpcx_aby3_bit_inject_p0_pre: NULL pointer");
+    void *ws;
+    MPCX_TRY(mpcx_ws(ctx, 72 * n, &ws));
+    u64 *s01 = (u64 *)ws, *s20 = s01 + 6 * n;
+    MPCX_TRY(prg_fill_words(ctx, seed01, 0, PRG_POP_T0 + pop01, 6 * n, 1, (i64 *)s01, nullptr));
+    MPCX_TRY(prg_fill_words(ctx, seed20, 0, PRG_POP_T0 + pop20, 3 * n, 1, (i64 *)s20, nullptr));
+    u64 *m1 = (u64 *)to_p1, *m2 = (u64 *)to_p2;
+    return ew_launch(ctx, n, [=] __device__(u64 i) {
+        const u64 cc = s01[i] + s20[i];
+        const u64 a = (u64)A0[i];
+        const i64 t = (i64)(B0[i] ^ B1[i]);
+        const u64 M0 = (u64)(0 ^ t) * a - cc, M1 = (u64)(1 ^ t) * a - cc; // ABY3Engine.cpp:547-548
+        m1[i] = M0 ^ s20[n + 2 * i];
+        m1[n + i] = M1 ^ s20[n + 2 * i + 1];
+        m2[i] = M0 ^ s01[n + 2 * i];
+        m2[n + i] = M1 ^ s01[n + 2 * i + 1];
+        m2[2 * n + i] = B0[i] == 1 ? s01[4 * n + 2 * i + 1] : s01[4 * n + 2 * i]; // :603
+    });
+}
+int mpcx_aby3_bit_inject_p0_post(mpcx_ctx *ctx, const int8_t *B0, uint64_t n, uint64_t seed01, uint64_t pop01,
+                                 uint64_t seed20, uint64_t pop20, const int64_t *from_p1, const int64_t *from_p2,
+                                 int64_t *C0, int64_t *C1) {
+    if (n == 0) return 0;
+    MPCX_REQUIRE(B0 && from_p1 && from_p2 && C0 && C1, "mpcx_aby3_bit_inject_p0_post: NULL pointer");
+    void *ws;
+    MPCX_TRY(mpcx_ws(ctx, 24 * n, &ws));
+    u64 *c01 = (u64 *)ws, *c10 = c01 + n, *c02 = c10 + n;
+    MPCX_TRY(prg_fill_words(ctx, seed01, 0, PRG_POP_T0 + pop01, n, 1, (i64 *)c01, nullptr));
+    MPCX_TRY(prg_fill_words(ctx, seed01, 0, PRG_POP_T0 + pop01 + 3 * n, n, 1, (i64 *)c10, nullptr));
+    MPCX_TRY(prg_fill_words(ctx, seed20, 0, PRG_POP_T0 + pop20, n, 1, (i64 *)c02, nullptr));
+    const u64 *f1 = (const u64 *)from_p1, *f2 = (const u64 *)from_p2;
+    u64 *o0 = (u64 *)C0, *o1 = (u64 *)C1;
+    return ew_launch(ctx, n, [=] __device__(u64 i) {
+        const u64 a12 = (B0[i] == 1 ? f1[n + i] : f1[i]) ^ f2[i]; // :660
+        o0[i] = c02[i] + a12;                                      // A0j[0] + A12j[0]
+        o1[i] = c01[i] + c10[i];                                   // A0j[1] + A12j[1]
+    });
+}
+int mpcx_aby3_bit_inject_p1_pre(mpcx_ctx *ctx, const int64_t *A0, const int64_t *A1, const int8_t *B0,
+                                const int8_t *B1, uint64_t n, uint64_t seed01, uint64_t pop01, uint64_t seed12,
+                                uint64_t pop12, int64_t *to_p0, int64_t *to_p2) {
+    if (n == 0) return 0;
+    MPCX_REQUIRE(A0 && A1 && B0 && B1 && to_p0 && to_p2, "mpcx_aby3_bit_inject_p1_pre: NULL pointer");
+    void *ws;
+    MPCX_TRY(mpcx_ws(ctx, 72 * n, &ws));
+    u64 *s01 = (u64 *)ws, *s12 = s01 + 6 * n;
+    MPCX_TRY(prg_fill_words(ctx, seed01, 0, PRG_POP_T0 + pop01, 6 * n, 1, (i64 *)s01, nullptr));
+    MPCX_TRY(prg_fill_words(ctx, seed12, 0, PRG_POP_T0 + pop12, 3 * n, 1, (i64 *)s12, nullptr));
+    u64 *m0 = (u64 *)to_p0, *m2 = (u64 *)to_p2;
+    return ew_launch(ctx, n, [=] __device__(u64 i) {
+        const u64 cc = s01[3 * n + i] + s12[i]; // C10 + C12
+        const u64 a = (u64)A0[i] + (u64)A1[i];
+        const i64 t = (i64)(B0[i] ^ B1[i]);
+        const u64 M0 = (u64)(0 ^ t) * a - cc, M1 = (u64)(1 ^ t) * a - cc; // :751-752
+        m2[i] = B1[i] == 1 ? s01[n + 2 * i + 1] : s01[n + 2 * i];         // :722
+        m2[n + i] = M0 ^ s01[4 * n + 2 * i];
+        m2[2 * n + i] = M1 ^ s01[4 * n + 2 * i + 1];
+        m0[i] = M0 ^ s12[n + 2 * i];
+        m0[n + i] = M1 ^ s12[n + 2 * i + 1];
+    });
+}
+int mpcx_aby3_bit_inject_p1_post(mpcx_ctx *ctx, const int8_t *B1, uint64_t n, uint64_t seed01, uint64_t pop01,
+                                 uint64_t seed12, uint64_t pop12, const int64_t *from_p0, const int64_t *from_p2,
+                                 int64_t *C0, int64_t *C1) {
+    if (n == 0) return 0;
+    MPCX_REQUIRE(B1 && from_p0 && from_p2 && C0 && C1, "mpcx_aby3_bit_inject_p1_post: NULL pointer");
+    void *ws;
+    MPCX_TRY(mpcx_ws(ctx, 24 * n, &ws));
+    u64 *c01 = (u64 *)ws, *c10 = c01 + n, *c12 = c10 + n;
+    MPCX_TRY(prg_fill_words(ctx, seed01, 0, PRG_POP_T0 + pop01, n, 1, (i64 *)c01, nullptr));
+    MPCX_TRY(prg_fill_words(ctx, seed01, 0, PRG_POP_T0 + pop01 + 3 * n, n, 1, (i64 *)c10, nullptr));
+    MPCX_TRY(prg_fill_words(ctx, seed12, 0, PRG_POP_T0 + pop12, n, 1, (i64 *)c12, nullptr));
+    const u64 *f0 = (const u64 *)from_p0, *f2 = (const u64 *)from_p2;
+    u64 *o0 = (u64 *)C0, *o1 = (u64 *)C1;
+    return ew_launch(ctx, n, [=] __device__(u64 i) {
+        const u64 a0 = (B1[i] == 1 ? f0[n + i] : f0[i]) ^ f2[i]; // :811
+        o0[i] = c01[i] + c10[i];                                  // A0j[0] + A12j[0]
+        o1[i] = a0 + c12[i];                                      // A0j[1] + A12j[1]
+    });
+}
+int mpcx_aby3_bit_inject_p2_pre(mpcx_ctx *ctx, const int8_t *B0, const int8_t *B1, uint64_t n, uint64_t seed20,
+                                uint64_t pop20, uint64_t seed12, uint64_t pop12, int64_t *to_p0, int64_t *to_p1) {
+    if (n == 0) return 0;
+    MPCX_REQUIRE(B0 && B1 && to_p0 && to_p1, "mpcx_aby3_bit_inject_p2_pre: NULL pointer");
+    void *ws;
+    MPCX_TRY(mpcx_ws(ctx, 32 * n, &ws));
+    u64 *w02 = (u64 *)ws, *w12 = w02 + 2 * n;
+    MPCX_TRY(prg_fill_words(ctx, seed20, 0, PRG_POP_T0 + pop20 + n, 2 * n, 1, (i64 *)w02, nullptr));
+    MPCX_TRY(prg_fill_words(ctx, seed12, 0, PRG_POP_T0 + pop12 + n, 2 * n, 1, (i64 *)w12, nullptr));
+    u64 *m0 = (u64 *)to_p0, *m1 = (u64 *)to_p1;
+    return ew_launch(ctx, n, [=] __device__(u64 i) {
+        m1[i] = B0[i] == 1 ? w02[2 * i + 1] : w02[2 * i]; // :888
+        m0[i] = B1[i] == 1 ? w12[2 * i + 1] : w12[2 * i]; // :922
+    });
+}
+int mpcx_aby3_bit_inject_p2_post(mpcx_ctx *ctx, const int8_t *B0, const int8_t *B1, uint64_t n, uint64_t seed20,
+                                 uint64_t pop20, uint64_t seed12, uint64_t pop12, const int64_t *from_p0,
+                                 const int64_t *from_p1, int64_t *C0, int64_t *C1) {
+    if (n == 0) return 0;
+    MPCX_REQUIRE(B0 && B1 && from_p0 && from_p1 && C0 && C1, "mpcx_aby3_bit_inject_p2_post: NULL pointer");
+    void *ws;
+    MPCX_TRY(mpcx_ws(ctx, 16 * n, &ws));
+    u64 *c02 = (u64 *)ws, *c12 = c02 + n;
+    MPCX_TRY(prg_fill_words(ctx, seed20, 0, PRG_POP_T0 + pop20, n, 1, (i64 *)c02, nullptr));
+    MPCX_TRY(prg_fill_words(ctx, seed12, 0, PRG_POP_T0 + pop12, n, 1, (i64 *)c12, nullptr));
+    const u64 *f0 = (const u64 *)from_p0, *f1 = (const u64 *)from_p1;
+    u64 *o0 = (u64 *)C0, *o1 = (u64 *)C1;
+    return ew_launch(ctx, n, [=] __device__(u64 i) {
+        const u64 a0 = (B0[i] == 1 ? f0[n + i] : f0[i]) ^ f1[i];                   // :963
+        const u64 a12 = (B1[i] == 1 ? f1[2 * n + i] : f1[n + i]) ^ f0[2 * n + i];  // :996
+        o0[i] = a0 + c12[i];  // A0j[0] + A12j[0]
+        o1[i] = c02[i] + a12; // A0j[1] + A12j[1]
+    });
+}
+
+} // extern "C"

@@ -1,0 +1,129 @@
+// Context, memory and error plumbing of libmpcx.
+#include <cstdarg>
+#include <mutex>
+
+#include "mpcx_internal.h"
+
+static thread_local std::string g_init_err;
+
+int mpcx_fail(mpcx_ctx *ctx, const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx)
+        ctx->err = buf;
+    else
+        g_init_err = buf;
+    return 1;
+}
+
+int mpcx_ws(mpcx_ctx *ctx, u64 bytes, void **out) {
+    if (bytes > ctx->ws_bytes) {
+        MPCX_HIP(hipSetDevice(ctx->device));
+        if (ctx->ws) {
+            // kernels of earlier calls may still read the old workspace
+            MPCX_HIP(hipStreamSynchronize(ctx->stream));
+            MPCX_HIP(hipFree(ctx->ws));
+            ctx->ws = nullptr;
+            ctx->ws_bytes = 0;
+        }
+        u64 want = (bytes + (1ull << 20) - 1) & ~((1ull << 20) - 1);
+        MPCX_HIP(hipMalloc(&ctx->ws, want));
+        ctx->ws_bytes = want;
+    }
+    *out = ctx->ws;
+    return 0;
+}
+
+extern "C" {
+
+int mpcx_init(int device, mpcx_ctx **out) {
+    mpcx_ctx *ctx = nullptr;
+    if (!out) return mpcx_fail(nullptr, "mpcx_init: out is NULL");
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0)
+        return mpcx_fail(nullptr, "mpcx_init: no HIP device available (%s)", hipGetErrorString(e));
+    if (device < 0 || device >= count) return mpcx_fail(nullptr, "mpcx_init: device %d out of range (%d devices)", device, count);
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) return mpcx_fail(nullptr, "mpcx_init: hipGetDeviceProperties: %s", hipGetErrorString(e));
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+        return mpcx_fail(nullptr, "mpcx_init: device %d is %s; this library is built for gfx950 (MI355X) only", device,
+                         prop.gcnArchName);
+    ctx = new mpcx_ctx();
+    ctx->device = device;
+    e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete ctx;
+        return mpcx_fail(nullptr, "mpcx_init: stream creation failed: %s", hipGetErrorString(e));
+    }
+    ctx->own_stream = true;
+    *out = ctx;
+    return 0;
+}
+
+int mpcx_shutdown(mpcx_ctx *ctx) {
+    if (!ctx) return 0;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    if (ctx->ws) hipFree(ctx->ws);
+    if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return 0;
+}
+
+const char *mpcx_last_error(mpcx_ctx *ctx) { return ctx ? ctx->err.c_str() : g_init_err.c_str(); }
+
+int mpcx_set_stream(mpcx_ctx *ctx, void *hip_stream) {
+    if (ctx->own_stream && ctx->stream) {
+        MPCX_HIP(hipStreamSynchronize(ctx->stream));
+        MPCX_HIP(hipStreamDestroy(ctx->stream));
+    }
+    ctx->stream = (hipStream_t)hip_stream;
+    ctx->own_stream = false;
+    return 0;
+}
+void *mpcx_get_stream(mpcx_ctx *ctx) { return (void *)ctx->stream; }
+
+int mpcx_sync(mpcx_ctx *ctx) {
+    MPCX_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+int mpcx_malloc(mpcx_ctx *ctx, uint64_t bytes, void **out) {
+    MPCX_HIP(hipSetDevice(ctx->device));
+    MPCX_HIP(hipMalloc(out, bytes ? bytes : 8));
+    return 0;
+}
+int mpcx_free(mpcx_ctx *ctx, void *p) {
+    if (!p) return 0;
+    MPCX_HIP(hipStreamSynchronize(ctx->stream));
+    MPCX_HIP(hipFree(p));
+    return 0;
+}
+int mpcx_h2d(mpcx_ctx *ctx, void *dst, const void *src, uint64_t bytes) {
+    if (!bytes) return 0;
+    MPCX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    MPCX_HIP(hipStreamSynchronize(ctx->stream)); // the host buffer may be pageable and reused at once
+    return 0;
+}
+int mpcx_d2h(mpcx_ctx *ctx, void *dst, const void *src, uint64_t bytes) {
+    if (!bytes) return 0;
+    MPCX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    MPCX_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+int mpcx_d2d(mpcx_ctx *ctx, void *dst, const void *src, uint64_t bytes) {
+    if (!bytes) return 0;
+    MPCX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return 0;
+}
+int mpcx_reserve_workspace(mpcx_ctx *ctx, uint64_t bytes) {
+    void *p;
+    return mpcx_ws(ctx, bytes, &p);
+}
+
+} // extern "C"

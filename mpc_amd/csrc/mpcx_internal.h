@@ -1,0 +1,72 @@
+// Internal declarations shared by the HIP translation units of libmpcx (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+
+#include "../../include/mpcx.h"
+
+typedef uint64_t u64;
+typedef int64_t i64;
+typedef uint32_t u32;
+typedef int32_t i32;
+typedef uint16_t u16;
+typedef int8_t i8;
+typedef uint8_t u8;
+
+// One checkpoint of a prvhash stream: the generator state before stream word t = 256 * index,
+// where stream word t is raw output #(5 + t) of PRgenerator(seed, lcg) (utils/PRgenerator.cpp:21-33).
+struct PrgCk {
+    u64 seed, lcg, hash, pad;
+};
+constexpr u64 PRG_CK = 256;        // stream words per checkpoint
+constexpr u64 PRG_POP_T0 = 320000; // stream word of the first pop (2 * BUFF_NUM, utils/PRgenerator.hpp:6)
+
+struct mpcx_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+    void *ws = nullptr; // scratch workspace, grown on demand
+    u64 ws_bytes = 0;
+};
+
+int mpcx_fail(mpcx_ctx *ctx, const char *fmt, ...);
+// scratch of at least `bytes`, 256-byte aligned, valid until the next mpcx_ws call on this context
+int mpcx_ws(mpcx_ctx *ctx, u64 bytes, void **out);
+// device pointer to the checkpoint table of (seed,lcg) covering stream words [0, t_end)
+int mpcx_prg_table(mpcx_ctx *ctx, u64 seed, u64 lcg, u64 t_end, const PrgCk **dev);
+
+#define MPCX_HIP(call)                                                                                                 \
+    do {                                                                                                               \
+        hipError_t e_ = (call);                                                                                        \
+        if (e_ != hipSuccess) return mpcx_fail(ctx, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+#define MPCX_TRY(call)                                                                                                 \
+    do {                                                                                                               \
+        int r_ = (call);                                                                                               \
+        if (r_) return r_;                                                                                             \
+    } while (0)
+#define MPCX_REQUIRE(cond, ...)                                                                                        \
+    do {                                                                                                               \
+        if (!(cond)) return mpcx_fail(ctx, __VA_ARGS__);                                                               \
+    } while (0)
+#define MPCX_LAUNCH_CHECK() MPCX_HIP(hipGetLastError())
+
+// internal launchers used across translation units (all asynchronous on ctx->stream)
+int prg_fill_words(mpcx_ctx *ctx, u64 seed, u64 lcg, u64 t_first, u64 count, u64 stride, i64 *out, i8 *bools);
+int prg_fill_buff_mod67(mpcx_ctx *ctx, u64 seed, u64 lcg, u64 first, u64 count, int zero_to_one, u8 *out);
+static inline u64 ceil_div(u64 a, u64 b) { return (a + b - 1) / b; }
+
+// Z (+)= [A_1 | A_2 | ..] * [B_1 (+Bplus_1) ; B_2 ; ..] (+ add - sub): a ring product whose K dimension is the
+// concatenation of `nparts` (A_p : r x l, B_p : l x c) pairs.  add/sub are row-major r*c word arrays.
+struct GemmPart {
+    const i64 *A;
+    const i64 *B, *Bplus; // Bplus (nullable) is added element-wise to B before the limb split
+};
+int ring_gemm_parts(mpcx_ctx *ctx, const GemmPart *parts, int nparts, u64 r, u64 l, u64 c, int layA, int layB,
+                    const i64 *add, const i64 *sub, i64 *Z, int layZ, int accumulate);
+// workspace bytes ring_gemm_parts takes from the front of the context workspace (a caller may reserve
+// more and use the tail for itself)
+u64 ring_gemm_ws_bytes(int nparts, u64 r, u64 l, u64 c);

@@ -1,0 +1,199 @@
+// On-device regeneration of the reference PRgenerator streams (utils/PRgenerator.cpp:3-42).
+//
+// prvhash-core64 has no jump-ahead (the state advances through a data-dependent multiply), so the
+// stream is made parallel with a checkpoint table: the host walks the stream once and keeps the
+// 24-byte state every PRG_CK = 256 outputs; one GPU lane then replays one 256-word segment.  A
+// 256-thread workgroup therefore owns 256 segments (512 KiB of output); every 16 steps the lanes
+// park their words in LDS and the workgroup writes them out as whole 128-byte lines.
+#include <map>
+#include <mutex>
+#include <vector>
+
+#include "mpcx_internal.h"
+
+namespace {
+
+struct HostState {
+    u64 seed, lcg, hash;
+};
+__host__ __device__ inline u64 prv_step(u64 &seed, u64 &lcg, u64 &hash) {
+    seed *= lcg * 2 + 1;
+    const u64 rs = seed >> 32 | seed << 32;
+    hash += rs + 0xAAAAAAAAAAAAAAAAull;
+    lcg += seed + 0x5555555555555555ull;
+    seed ^= hash;
+    return lcg ^ rs;
+}
+
+struct Table {
+    std::vector<PrgCk> host; // host[e] = state before stream word 256*e
+    PrgCk *dev = nullptr;
+    u64 dev_cap = 0, dev_count = 0;
+    std::vector<PrgCk *> retired; // older device copies a kernel in flight may still read
+};
+struct Key {
+    int device;
+    u64 seed, lcg;
+    bool operator<(const Key &o) const {
+        if (device != o.device) return device < o.device;
+        if (seed != o.seed) return seed < o.seed;
+        return lcg < o.lcg;
+    }
+};
+std::mutex g_mu;
+std::map<Key, Table> g_tables;
+
+// mode 0: every stream word -> out64[rel]                                  (pop stream)
+// mode 1: even words -> out64[rel/2], odd words' low bit -> out8[rel/2]     (int_buff / bool_buff)
+// mode 2: even words -> out8[rel/2] = (uint16)word % 67                     (Z_67 shares drawn from int_buff)
+// mode 3: as mode 2 with 0 mapped to 1                                      (privateCompare's s and u)
+__global__ __launch_bounds__(256) void prg_fill_kernel(const PrgCk *__restrict__ ck, u64 seg0, u64 nseg, u64 t_first,
+                                                       u64 t_end, int mode, u64 *__restrict__ out64,
+                                                       u8 *__restrict__ out8) {
+    __shared__ u64 tile[256 * 17];
+    const u32 tid = threadIdx.x;
+    const u64 blk_seg0 = seg0 + (u64)blockIdx.x * 256;
+    const u64 seg = blk_seg0 + tid;
+    const bool active = seg < seg0 + nseg;
+    u64 seed = 0, lcg = 0, hash = 0;
+    if (active) {
+        PrgCk c = ck[seg];
+        seed = c.seed;
+        lcg = c.lcg;
+        hash = c.hash;
+    }
+    for (u32 it = 0; it < 16; it++) {
+#pragma unroll
+        for (u32 k = 0; k < 16; k++) tile[tid * 17 + k] = prv_step(seed, lcg, hash);
+        __syncthreads();
+#pragma unroll 4
+        for (u32 j = 0; j < 16; j++) {
+            const u32 idx = j * 256 + tid;
+            const u32 row = idx >> 4, col = idx & 15;
+            const u64 t = (blk_seg0 + row) * PRG_CK + it * 16 + col;
+            if (t >= t_first && t < t_end) {
+                const u64 v = tile[row * 17 + col];
+                const u64 rel = t - t_first;
+                if (mode == 0) {
+                    out64[rel] = v;
+                } else if ((rel & 1) == 0) {
+                    if (mode == 1) {
+                        if (out64) out64[rel >> 1] = v;
+                    } else {
+                        u32 m = (u32)(v & 0xFFFF) % 67u;
+                        if (mode == 3 && m == 0) m = 1;
+                        out8[rel >> 1] = (u8)m;
+                    }
+                } else if (mode == 1 && out8) {
+                    out8[rel >> 1] = (u8)(v & 1);
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+} // namespace
+
+int mpcx_prg_table(mpcx_ctx *ctx, u64 seed, u64 lcg, u64 t_end, const PrgCk **dev) {
+    std::lock_guard<std::mutex> g(g_mu);
+    Table &T = g_tables[Key{ctx->device, seed, lcg}];
+    if (T.host.empty()) {
+        u64 s = seed, l = lcg, h = 0;
+        for (int i = 0; i < 5; i++) prv_step(s, l, h); // utils/PRgenerator.cpp:23-26
+        T.host.push_back(PrgCk{s, l, h, 0});
+    }
+    const u64 need = t_end / PRG_CK + 1; // checkpoints 0 .. floor(t_end/256)
+    if (T.host.size() < need) {
+        T.host.reserve(need);
+        PrgCk c = T.host.back();
+        while (T.host.size() < need) {
+            for (u64 i = 0; i < PRG_CK; i++) prv_step(c.seed, c.lcg, c.hash);
+            T.host.push_back(c);
+        }
+    }
+    if (T.dev_count < need) {
+        MPCX_HIP(hipSetDevice(ctx->device));
+        if (T.dev_cap < need) {
+            u64 cap = need + need / 4 + 1024;
+            PrgCk *nd = nullptr;
+            MPCX_HIP(hipMalloc((void **)&nd, cap * sizeof(PrgCk)));
+            if (T.dev) T.retired.push_back(T.dev);
+            T.dev = nd;
+            T.dev_cap = cap;
+            T.dev_count = 0;
+        }
+        MPCX_HIP(hipMemcpy(T.dev + T.dev_count, T.host.data() + T.dev_count, (need - T.dev_count) * sizeof(PrgCk),
+                           hipMemcpyHostToDevice));
+        T.dev_count = need;
+    }
+    *dev = T.dev;
+    return 0;
+}
+
+static int prg_launch(mpcx_ctx *ctx, u64 seed, u64 lcg, u64 t_first, u64 t_end, int mode, u64 *out64, u8 *out8) {
+    const PrgCk *ck;
+    MPCX_TRY(mpcx_prg_table(ctx, seed, lcg, t_end, &ck));
+    const u64 seg0 = t_first / PRG_CK, seg1 = (t_end - 1) / PRG_CK;
+    const u64 nseg = seg1 - seg0 + 1;
+    const u64 grid = ceil_div(nseg, 256);
+    MPCX_REQUIRE(grid < (1ull << 31), "prg fill: range too large for one launch");
+    hipLaunchKernelGGL(prg_fill_kernel, dim3((u32)grid), dim3(256), 0, ctx->stream, ck, seg0, nseg, t_first, t_end, mode,
+                       out64, out8);
+    MPCX_LAUNCH_CHECK();
+    return 0;
+}
+
+// words at stream positions t_first + stride*i, i in [0,count) -> out[i]; with stride 2 the odd
+// positions' low bits -> bools[i]
+int prg_fill_words(mpcx_ctx *ctx, u64 seed, u64 lcg, u64 t_first, u64 count, u64 stride, i64 *out, i8 *bools) {
+    if (count == 0) return 0;
+    MPCX_REQUIRE(stride == 1 || stride == 2, "prg_fill_words: stride must be 1 or 2");
+    MPCX_REQUIRE(out || bools, "prg_fill_words: no output buffer");
+    MPCX_REQUIRE(stride == 2 || out, "prg_fill_words: pop fill needs an output buffer");
+    return prg_launch(ctx, seed, lcg, t_first, t_first + stride * count, stride == 1 ? 0 : 1, (u64 *)out, (u8 *)bools);
+}
+
+// out[i] = (uint16)int_buff[first + i] % 67 (zero_to_one: 0 -> 1), one byte per value
+int prg_fill_buff_mod67(mpcx_ctx *ctx, u64 seed, u64 lcg, u64 first, u64 count, int zero_to_one, u8 *out) {
+    if (count == 0) return 0;
+    MPCX_REQUIRE(out, "prg_fill_buff_mod67: out is NULL");
+    return prg_launch(ctx, seed, lcg, 2 * first, 2 * first + 2 * count - 1, zero_to_one ? 3 : 2, nullptr, out);
+}
+
+extern "C" {
+
+int mpcx_prg_ckpt_build(mpcx_ctx *ctx, uint64_t seed, uint64_t lcg, uint64_t n_pops, uint64_t n_buff) {
+    u64 t_end = 2 * n_buff;
+    if (n_pops && PRG_POP_T0 + n_pops > t_end) t_end = PRG_POP_T0 + n_pops;
+    const PrgCk *ck;
+    return mpcx_prg_table(ctx, seed, lcg, t_end, &ck);
+}
+
+int mpcx_prg_fill_buff(mpcx_ctx *ctx, uint64_t seed, uint64_t lcg, uint64_t first, uint64_t count, int64_t *ints,
+                       int8_t *bools) {
+    return prg_fill_words(ctx, seed, lcg, 2 * first, count, 2, ints, bools);
+}
+
+int mpcx_prg_fill_pop(mpcx_ctx *ctx, uint64_t seed, uint64_t lcg, uint64_t first_pop, uint64_t count, int64_t *out) {
+    MPCX_REQUIRE(out || count == 0, "mpcx_prg_fill_pop: out is NULL");
+    return prg_fill_words(ctx, seed, lcg, PRG_POP_T0 + first_pop, count, 1, out, nullptr);
+}
+
+int mpcx_prg_state_at_pop(mpcx_ctx *ctx, uint64_t seed, uint64_t lcg, uint64_t pop_index, uint64_t state_out[3]) {
+    const u64 t = PRG_POP_T0 + pop_index;
+    const PrgCk *ck;
+    MPCX_TRY(mpcx_prg_table(ctx, seed, lcg, t, &ck));
+    PrgCk c;
+    {
+        std::lock_guard<std::mutex> g(g_mu);
+        c = g_tables[Key{ctx->device, seed, lcg}].host[t / PRG_CK];
+    }
+    for (u64 i = (t / PRG_CK) * PRG_CK; i < t; i++) prv_step(c.seed, c.lcg, c.hash);
+    state_out[0] = c.seed;
+    state_out[1] = c.lcg;
+    state_out[2] = c.hash;
+    return 0;
+}
+
+} // extern "C"

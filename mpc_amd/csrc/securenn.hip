@@ -1,0 +1,530 @@
+// Per-party local segments of SecurennEngine (mpc_engine/SecurennEngine.cpp) as HIP kernels.
+//
+// Z_67 bit shares travel as 64 uint16 per element (128 B, LSB first).  The privateCompare kernels
+// give each element to 8 adjacent lanes (16 bytes = 8 bit positions per lane), so a wavefront moves
+// 8 whole elements per 1 KiB load/store and the running sum over bit positions is a short suffix
+// scan across the 8 lanes of a group.  Randomness that the reference reads from PRgenerator::int_buff
+// is regenerated on the device from the stream checkpoints.
+#include "mpcx_internal.h"
+
+namespace {
+
+constexpr u64 L_1 = ~0ull; // utils/util.hpp:12
+constexpr u32 P = 67;      // utils/util.hpp:11
+
+// SecurennEngine.cpp:15-28
+__device__ inline u64 add_L_1(u64 a, u64 b) {
+    const u64 c = a + b;
+    const u64 carry = c < a;
+    return (c + carry) % L_1;
+}
+__device__ inline u64 sub_L_1(u64 a, u64 b) { return add_L_1(a, (L_1 - b) % L_1); }
+
+template <class F> __global__ __launch_bounds__(256) void ew_kernel(u64 n, F f) {
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256) f(i);
+}
+template <class F> int ew_launch(mpcx_ctx *ctx, u64 n, F f) {
+    if (n == 0) return 0;
+    u64 blocks = ceil_div(n, 256);
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(ew_kernel<F>, dim3((u32)blocks), dim3(256), 0, ctx->stream, n, f);
+    MPCX_LAUNCH_CHECK();
+    return 0;
+}
+
+struct u16x8 {
+    u32 w[4];
+    __device__ u32 get(int j) const { return (w[j >> 1] >> (16 * (j & 1))) & 0xFFFF; }
+    __device__ void set(int j, u32 v) { w[j >> 1] = (w[j >> 1] & ~(0xFFFFu << (16 * (j & 1)))) | (v << (16 * (j & 1))); }
+};
+
+// privateCompare, party 0/1 (SecurennEngine.cpp:543-592).  One piece = 8 bit positions of one element.
+// S / U: one byte per value, already reduced mod 67 with 0 -> 1 (:523-534).
+__global__ __launch_bounds__(256) void pc_party_kernel(int party, const uint4 *__restrict__ xbits, const i8 *__restrict__ beta,
+                                                       const i64 *__restrict__ r, const u64 *__restrict__ S,
+                                                       const u64 *__restrict__ U, u64 n, uint4 *__restrict__ d_out) {
+    const u64 pieces = n * 8;
+    const u64 stride = (u64)gridDim.x * 256;
+    const u32 pid = (u32)party;
+    for (u64 base = (u64)blockIdx.x * 256; base < pieces; base += stride) {
+        const u64 c = base + threadIdx.x; // pieces is a multiple of 8, so groups of 8 lanes are all-live or all-dead
+        const bool live = c < pieces;
+        const u64 i = live ? c >> 3 : 0;
+        const u32 q = (u32)(c & 7);
+        u16x8 x{}, d{};
+        u64 sb = 0, ub = 0;
+        u64 rv = 0;
+        int bt = 0;
+        if (live) {
+            const uint4 xv = xbits[c];
+            x.w[0] = xv.x, x.w[1] = xv.y, x.w[2] = xv.z, x.w[3] = xv.w;
+            sb = S[c];
+            rv = (u64)r[i];
+            bt = beta[i];
+        }
+        const u64 tv = rv + 1;
+        const int mode = (bt == 0) ? 0 : ((bt == 1 && rv != ~0ull) ? 1 : 2);
+        u32 wv[8], cv[8];
+        u32 tot = 0;
+        if (mode != 2) {
+            const u64 bits = mode == 0 ? rv : tv;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const u32 xk = x.get(j);
+                const u32 b = (u32)((bits >> (8 * q + j)) & 1);
+                // W = X + party*b + 65*b*X, stored to uint16 then % 67 (:561-562, :569-570)
+                wv[j] = ((xk + pid * b + (P - 2) * b * xk) & 0xFFFF) % P;
+                tot += wv[j];
+            }
+        }
+        // sum of W over all higher bit positions: suffix scan over the 8 lanes of the element
+        u32 incl = tot;
+#pragma unroll
+        for (u32 dlt = 1; dlt < 8; dlt <<= 1) {
+            const u32 t = __shfl_down(incl, dlt, 8);
+            if (q + dlt < 8) incl += t;
+        }
+        u32 run = incl - tot; // W of the lanes above this one
+        if (mode == 2 && live) ub = U[c];
+#pragma unroll
+        for (int j = 7; j >= 0; j--) {
+            const u32 xk = x.get(j);
+            u32 ck;
+            if (mode == 0) {
+                const u32 b = (u32)((rv >> (8 * q + j)) & 1);
+                ck = ((xk * (P - 1)) % P + pid * b + pid + (run & 0xFFFF)) & 0xFFFF; // :559
+                ck %= P;
+                run += wv[j];
+            } else if (mode == 1) {
+                const u32 b = (u32)((tv >> (8 * q + j)) & 1);
+                ck = ((P - 1) * pid * b + xk + pid + (run & 0xFFFF)) & 0xFFFF; // :567
+                ck %= P;
+                run += wv[j];
+            } else {
+                const u32 uk = (u32)((ub >> (8 * j)) & 0xFF);
+                if (q != 0 || j != 0)
+                    ck = (((1 - pid) * (1 + uk) + (P - pid) * uk) & 0xFFFF) % P; // :577-578
+                else
+                    ck = pid == 0 ? uk : P - uk; // :582
+            }
+            const u32 sk = (u32)((sb >> (8 * j)) & 0xFF);
+            d.set(j, ((sk * ck) & 0xFFFF) % P); // :589-590
+        }
+        if (live) d_out[c] = make_uint4(d.w[0], d.w[1], d.w[2], d.w[3]);
+    }
+}
+
+// privateCompare, party 2 (:655-669): beta'[i] = any_k((d0[i][k] + d1[i][k]) % 67 == 0)
+__global__ __launch_bounds__(256) void pc_helper_kernel(const uint4 *__restrict__ d0, const uint4 *__restrict__ d1, u64 n,
+                                                        i8 *__restrict__ beta_out) {
+    const u64 pieces = n * 8;
+    const u64 stride = (u64)gridDim.x * 256;
+    for (u64 base = (u64)blockIdx.x * 256; base < pieces; base += stride) {
+        const u64 c = base + threadIdx.x;
+        const bool live = c < pieces;
+        bool hit = false;
+        if (live) {
+            const uint4 a = d0[c], b = d1[c];
+            const u32 aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const u32 s = ((aw[j >> 1] >> (16 * (j & 1))) + (bw[j >> 1] >> (16 * (j & 1)))) & 0xFFFF;
+                hit |= (s % P) == 0;
+            }
+        }
+        const u64 m = __ballot(hit); // 8 lanes per element, 8 elements per wavefront
+        const u32 lane = threadIdx.x & 63;
+        if (live && (lane & 7) == 0) beta_out[c >> 3] = (i8)(((m >> lane) & 0xFF) != 0);
+    }
+}
+
+// Z_67 sharing of the 64 bits of v[i] (:835-842 / :919-927): rnd = one random byte (already % 67) per bit;
+// first[i][k] = rnd, second[i][k] = (bit + 67 - rnd) % 67
+__global__ __launch_bounds__(256) void bit_share_kernel(const u64 *__restrict__ v, const u64 *__restrict__ rnd, u64 n,
+                                                        uint4 *__restrict__ first, uint4 *__restrict__ second) {
+    const u64 pieces = n * 8;
+    for (u64 c = (u64)blockIdx.x * 256 + threadIdx.x; c < pieces; c += (u64)gridDim.x * 256) {
+        const u64 val = v[c >> 3];
+        const u32 q = (u32)(c & 7);
+        const u64 rb = rnd[c];
+        u16x8 a{}, b{};
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const u32 s = (u32)((rb >> (8 * j)) & 0xFF);
+            const u32 bit = (u32)((val >> (8 * q + j)) & 1);
+            a.set(j, s);
+            b.set(j, (bit + P - s) % P);
+        }
+        first[c] = make_uint4(a.w[0], a.w[1], a.w[2], a.w[3]);
+        second[c] = make_uint4(b.w[0], b.w[1], b.w[2], b.w[3]);
+    }
+}
+
+inline u32 grid_for(u64 work) {
+    u64 b = ceil_div(work, 256);
+    if (b > 8192) b = 8192;
+    if (b == 0) b = 1;
+    return (u32)b;
+}
+
+// the (r0, r1) -> R, r1', alpha bookkeeping of shareConvert (:700-710)
+struct ScRand {
+    u64 R, r0, r1;
+};
+__device__ inline ScRand sc_rand(u64 w0, u64 w1) {
+    ScRand o{w0 + w1, w0, w1};
+    if (o.R == 0) {
+        o.R += 1;
+        o.r1 += 1;
+    }
+    return o;
+}
+
+} // namespace
+
+extern "C" {
+
+int mpcx_snn_share_local(mpcx_ctx *ctx, int party, const int64_t *X, uint64_t n, uint64_t seed01, uint64_t pop01,
+                         int64_t *out) {
+    if (n == 0) return 0;
+    MPCX_REQUIRE(party >= 0 && party <= 2, "mpcx_snn_share_local: party %d", party);
+    MPCX_REQUIRE(out && (party != 1 || X), "mpcx_snn_share_local: NULL pointer");
+    if (party == 2) {
+        MPCX_HIP(hipMemsetAsync(out, 0, 8 * n, ctx->stream));
+        return 0;
+    }
+    void *ws;
+    MPCX_TRY(mpcx_ws(ctx, 8 * n, &ws));
+    u64 *w = (u64 *)ws;
+    MPCX_TRY(prg_fill_words(ctx, seed01, 0, PRG_POP_T0 + pop01, n, 1, (i64 *)w, nullptr));
+    u64 *o = (u64 *)out;
+    const u64 *x = (const u64 *)X;
+    if (party == 0) return ew_launch(ctx, n, [=] __device__(u64 i) { o[i] = 0 - w[i]; });
+    return ew_launch(ctx, n, [=] __device__(u64 i) { o[i] = x[i] + w[i]; });
+}
+
+int mpcx_snn_add_L1(mpcx_ctx *ctx, const int64_t *a, const int64_t *b, int64_t *out, uint64_t n) {
+    MPCX_REQUIRE((a && b && out) || n == 0, "mpcx_snn_add_L1: NULL pointer");
+    return ew_launch(ctx, n, [=] __device__(u64 i) { out[i] = (i64)add_L_1((u64)a[i], (u64)b[i]); });
+}
+int mpcx_snn_add_zp(mpcx_ctx *ctx, const uint16_t *a, const uint16_t *b, uint16_t *out, uint64_t n64) {
+    MPCX_REQUIRE((a && b && out) || n64 == 0, "mpcx_snn_add_zp: NULL pointer");
+    return ew_launch(ctx, n64, [=] __device__(u64 i) { out[i] = (u16)(((u32)(a[i] + b[i]) & 0xFFFF) % P); });
+}
+
+// ---- Beaver matmul
+int mpcx_snn_beaver_dealer_matmul(mpcx_ctx *ctx, uint64_t seedS, uint64_t r, uint64_t l, uint64_t c, int64_t *msg0,
+                                  int64_t *msg1) {
+    MPCX_REQUIRE(msg0 && msg1, "mpcx_snn_beaver_dealer_matmul: NULL pointer");
+    MPCX_REQUIRE(r && l && c, "mpcx_snn_beaver_dealer_matmul: empty shape");
+    const u64 na = r * l, nb = l * c, nc = r * c;
+    // SecurennEngine.cpp:80,92,103: A_i, B_i, C_0 are consecutive slices of the self stream's buffer
+    MPCX_TRY(prg_fill_words(ctx, seedS, 0, 0, na, 2, msg0, nullptr));
+    MPCX_TRY(prg_fill_words(ctx, seedS, 0, 2 * na, na, 2, msg1, nullptr));
+    MPCX_TRY(prg_fill_words(ctx, seedS, 0, 2 * (2 * na), nb, 2, msg0 + na, nullptr));
+    MPCX_TRY(prg_fill_words(ctx, seedS, 0, 2 * (2 * na + nb), nb, 2, msg1 + na, nullptr));
+    MPCX_TRY(prg_fill_words(ctx, seedS, 0, 2 * (2 * na + 2 * nb), nc, 2, msg0 + na + nb, nullptr));
+    // C_1 = (A_0 + A_1)(B_0 + B_1) - C_0  (:106-107)
+    const u64 gemm_bytes = ring_gemm_ws_bytes(1, r, l, c);
+    void *ws;
+    MPCX_TRY(mpcx_ws(ctx, gemm_bytes + 8 * na, &ws));
+    u64 *As = (u64 *)((u8 *)ws + gemm_bytes);
+    const u64 *a0 = (const u64 *)msg0, *a1 = (const u64 *)msg1;
+    MPCX_TRY(ew_launch(ctx, na, [=] __device__(u64 i) { As[i] = a0[i] + a1[i]; }));
+    GemmPart p{(const i64 *)As, msg0 + na, msg1 + na};
+    return ring_gemm_parts(ctx, &p, 1, r, l, c, 0, 0, nullptr, msg0 + na + nb, msg1 + na + nb, 0, 0);
+}
+
+int mpcx_snn_beaver_party_open_matmul(mpcx_ctx *ctx, const int64_t *X, const int64_t *Y, int layout,
+                                      const int64_t *triple, uint64_t r, uint64_t l, uint64_t c, int64_t *ef_out) {
+    MPCX_REQUIRE(X && Y && triple && ef_out, "mpcx_snn_beaver_party_open_matmul: NULL pointer");
+    MPCX_REQUIRE(r && l && c, "mpcx_snn_beaver_party_open_matmul: empty shape");
+    const u64 na = r * l, nb = l * c;
+    const u64 *x = (const u64 *)X, *y = (const u64 *)Y, *t = (const u64 *)triple;
+    u64 *o = (u64 *)ef_out;
+    return ew_launch(ctx, na + nb, [=] __device__(u64 i) { // :150-155, E | F row-major
+        if (i < na) {
+            const u64 row = i / l, col = i - row * l;
+            o[i] = x[layout ? col * r + row : i] - t[i];
+        } else {
+            const u64 j = i - na, row = j / c, col = j - row * c;
+            o[i] = y[layout ? col * l + row : j] - t[i];
+        }
+    });
+}
+
+int mpcx_snn_beaver_party_finish_matmul(mpcx_ctx *ctx, int party, const int64_t *triple, const int64_t *ef_own,
+                                        const int64_t *ef_peer, uint64_t r, uint64_t l, uint64_t c, int layoutZ,
+                                        int64_t *Z) {
+    MPCX_REQUIRE(party == 0 || party == 1, "mpcx_snn_beaver_party_finish_matmul: party %d", party);
+    MPCX_REQUIRE(triple && ef_own && ef_peer && Z, "mpcx_snn_beaver_party_finish_matmul: NULL pointer");
+    MPCX_REQUIRE(r && l && c, "mpcx_snn_beaver_party_finish_matmul: empty shape");
+    const u64 na = r * l, nb = l * c;
+    const u64 gemm_bytes = ring_gemm_ws_bytes(2, r, l, c);
+    void *ws;
+    MPCX_TRY(mpcx_ws(ctx, gemm_bytes + 8 * (na + nb), &ws));
+    u64 *EF = (u64 *)((u8 *)ws + gemm_bytes);
+    const u64 *a = (const u64 *)ef_own, *b = (const u64 *)ef_peer;
+    MPCX_TRY(ew_launch(ctx, na + nb, [=] __device__(u64 i) { EF[i] = a[i] + b[i]; })); // :165-166
+    // Z = C + E*B + A*F + party*E*F (:167) = C + [E | A] * [B + party*F ; F]
+    const i64 *A = triple, *B = triple + na, *C = triple + na + nb;
+    const i64 *E = (const i64 *)EF, *F = (const i64 *)(EF + na);
+    GemmPart parts[2] = {{E, B, party ? F : nullptr}, {A, F, nullptr}};
+    return ring_gemm_parts(ctx, parts, 2, r, l, c, 0, 0, C, nullptr, Z, layoutZ, 0);
+}
+
+// ---- Beaver vector product
+int mpcx_snn_beaver_dealer_vecmul(mpcx_ctx *ctx, uint64_t seedS, uint64_t n_total, uint64_t i0, uint64_t n,
+                                  int64_t *A0, int64_t *B0, int64_t *C0, int64_t *A1, int64_t *B1, int64_t *C1) {
+    if (n == 0) return 0;
+    MPCX_REQUIRE(A0 && B0 && C0 && A1 && B1 && C1, "mpcx_snn_beaver_dealer_vecmul: NULL pointer");
+    MPCX_REQUIRE(i0 + n <= n_total, "mpcx_snn_beaver_dealer_vecmul: range outside the vector");
+    void *ws;
+    MPCX_TRY(mpcx_ws(ctx, 48 * n, &ws));
+    u64 *w0 = (u64 *)ws, *w1 = w0 + 3 * n;
+    MPCX_TRY(prg_fill_words(ctx, seedS, 0, 2 * (3 * i0), 3 * n, 2, (i64 *)w0, nullptr));             // :191-193, i = 0
+    MPCX_TRY(prg_fill_words(ctx, seedS, 0, 2 * (3 * (n_total + i0)), 3 * n, 2, (i64 *)w1, nullptr)); // i = 1
+    return ew_launch(ctx, n, [=] __device__(u64 j) {
+        const u64 a0 = w0[3 * j], b0 = w0[3 * j + 1], c0 = w0[3 * j + 2], a1 = w1[3 * j], b1 = w1[3 * j + 1];
+        A0[j] = (i64)a0, B0[j] = (i64)b0, C0[j] = (i64)c0, A1[j] = (i64)a1, B1[j] = (i64)b1;
+        C1[j] = (i64)((a0 + a1) * (b0 + b1) - c0); // :198
+    });
+}
+int mpcx_snn_beaver_party_open_vecmul(mpcx_ctx *ctx, const int64_t *X, const int64_t *Y, const int64_t *A,
+                                      const int64_t *B, uint64_t n, int64_t *E, int64_t *F) {
+    MPCX_REQUIRE((X && Y && A && B && E && F) || n == 0, "mpcx_snn_beaver_party_open_vecmul: NULL pointer");
+    return ew_launch(ctx, n, [=] __device__(u64 i) {
+        E[i] = (i64)((u64)X[i] - (u64)A[i]);
+        F[i] = (i64)((u64)Y[i] - (u64)B[i]);
+    });
+}
+int mpcx_snn_beaver_party_finish_vecmul(mpcx_ctx *ctx, int party, const int64_t *A, const int64_t *B,
+                                        const int64_t *C, const int64_t *E_own, const int64_t *F_own,
+                                        const int64_t *E_peer, const int64_t *F_peer, uint64_t n, int64_t *Z) {
+    MPCX_REQUIRE(party == 0 || party == 1, "mpcx_snn_beaver_party_finish_vecmul: party %d", party);
+    MPCX_REQUIRE((A && B && C && E_own && F_own && E_peer && F_peer && Z) || n == 0,
+                 "mpcx_snn_beaver_party_finish_vecmul: NULL pointer");
+    const u64 pid = (u64)party;
+    return ew_launch(ctx, n, [=] __device__(u64 i) {
+        const u64 E = (u64)E_own[i] + (u64)E_peer[i], F = (u64)F_own[i] + (u64)F_peer[i];
+        Z[i] = (i64)((u64)C[i] + E * (u64)B[i] + F * (u64)A[i] + F * E * pid); // :294
+    });
+}
+
+// ---- privateCompare
+int mpcx_snn_pc_party(mpcx_ctx *ctx, int party, const uint16_t *xbits, const int8_t *beta, const int64_t *r,
+                      uint64_t n_total, uint64_t i0, uint64_t n, uint64_t seed01, uint16_t *d_out) {
+    if (n == 0) return 0;
+    MPCX_REQUIRE(party == 0 || party == 1, "mpcx_snn_pc_party: party %d", party);
+    MPCX_REQUIRE(xbits && beta && r && d_out, "mpcx_snn_pc_party: NULL pointer");
+    MPCX_REQUIRE(i0 + n <= n_total, "mpcx_snn_pc_party: range outside the vector");
+    MPCX_REQUIRE(((uintptr_t)xbits & 15) == 0 && ((uintptr_t)d_out & 15) == 0, "mpcx_snn_pc_party: xbits/d_out must be 16-byte aligned");
+    void *ws;
+    MPCX_TRY(mpcx_ws(ctx, 128 * n, &ws));
+    u8 *S = (u8 *)ws, *U = S + 64 * n;
+    MPCX_TRY(prg_fill_buff_mod67(ctx, seed01, 0, 64 * i0, 64 * n, 1, S));                // :523,525-529
+    MPCX_TRY(prg_fill_buff_mod67(ctx, seed01, 0, 64 * n_total + 64 * i0, 64 * n, 1, U)); // :524,530-534
+    hipLaunchKernelGGL(pc_party_kernel, dim3(grid_for(8 * n)), dim3(256), 0, ctx->stream, party, (const uint4 *)xbits, beta,
+                       r, (const u64 *)S, (const u64 *)U, n, (uint4 *)d_out);
+    MPCX_LAUNCH_CHECK();
+    return 0;
+}
+int mpcx_snn_pc_helper(mpcx_ctx *ctx, const uint16_t *d0, const uint16_t *d1, uint64_t n, int8_t *beta_out) {
+    if (n == 0) return 0;
+    MPCX_REQUIRE(d0 && d1 && beta_out, "mpcx_snn_pc_helper: NULL pointer");
+    MPCX_REQUIRE(((uintptr_t)d0 & 15) == 0 && ((uintptr_t)d1 & 15) == 0, "mpcx_snn_pc_helper: d0/d1 must be 16-byte aligned");
+    hipLaunchKernelGGL(pc_helper_kernel, dim3(grid_for(8 * n)), dim3(256), 0, ctx->stream, (const uint4 *)d0,
+                       (const uint4 *)d1, n, beta_out);
+    MPCX_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- shareConvert
+static int sc_rand_words(mpcx_ctx *ctx, u64 seed01, u64 n_total, u64 i0, u64 n, u64 **w0, u64 **w1, i8 **eta2) {
+    void *ws;
+    MPCX_TRY(mpcx_ws(ctx, 17 * n + 64, &ws));
+    *w0 = (u64 *)ws;
+    *w1 = *w0 + n;
+    *eta2 = (i8 *)(*w1 + n);
+    MPCX_TRY(prg_fill_words(ctx, seed01, 0, 2 * i0, n, 2, (i64 *)*w0, *eta2));                // :700-701
+    MPCX_TRY(prg_fill_words(ctx, seed01, 0, 2 * (n_total + i0), n, 2, (i64 *)*w1, nullptr)); // :702
+    return 0;
+}
+int mpcx_snn_sc_party_open(mpcx_ctx *ctx, int party, const int64_t *A, uint64_t n_total, uint64_t i0, uint64_t n,
+                           uint64_t seed01, int64_t *x_out) {
+    if (n == 0) return 0;
+    MPCX_REQUIRE(party == 0 || party == 1, "mpcx_snn_sc_party_open: party %d", party);
+    MPCX_REQUIRE(A && x_out, "mpcx_snn_sc_party_open: NULL pointer");
+    MPCX_REQUIRE(i0 + n <= n_total, "mpcx_snn_sc_party_open: range outside the vector");
+    u64 *w0, *w1;
+    i8 *e2;
+    MPCX_TRY(sc_rand_words(ctx, seed01, n_total, i0, n, &w0, &w1, &e2));
+    return ew_launch(ctx, n, [=] __device__(u64 i) {
+        const ScRand s = sc_rand(w0[i], w1[i]);
+        x_out[i] = (i64)((u64)A[i] + (party == 0 ? s.r0 : s.r1)); // :718
+    });
+}
+int mpcx_snn_sc_party_pc_inputs(mpcx_ctx *ctx, uint64_t n_total, uint64_t i0, uint64_t n, uint64_t seed01,
+                                int8_t *eta2_out, int64_t *rm1_out) {
+    if (n == 0) return 0;
+    MPCX_REQUIRE(eta2_out && rm1_out, "mpcx_snn_sc_party_pc_inputs: NULL pointer");
+    MPCX_REQUIRE(i0 + n <= n_total, "mpcx_snn_sc_party_pc_inputs: range outside the vector");
+    u64 *w0, *w1;
+    i8 *e2;
+    MPCX_TRY(sc_rand_words(ctx, seed01, n_total, i0, n, &w0, &w1, &e2));
+    return ew_launch(ctx, n, [=] __device__(u64 i) {
+        eta2_out[i] = e2[i];
+        rm1_out[i] = (i64)(sc_rand(w0[i], w1[i]).R - 1); // :738
+    });
+}
+int mpcx_snn_sc_party_finish(mpcx_ctx *ctx, int party, const int64_t *A, const int64_t *delta_j,
+                             const int64_t *eta1_j, uint64_t n_total, uint64_t i0, uint64_t n, uint64_t seed01,
+                             int64_t *y_out) {
+    if (n == 0) return 0;
+    MPCX_REQUIRE(party == 0 || party == 1, "mpcx_snn_sc_party_finish: party %d", party);
+    MPCX_REQUIRE(A && delta_j && eta1_j && y_out, "mpcx_snn_sc_party_finish: NULL pointer");
+    MPCX_REQUIRE(i0 + n <= n_total, "mpcx_snn_sc_party_finish: range outside the vector");
+    u64 *w0, *w1;
+    i8 *e2;
+    MPCX_TRY(sc_rand_words(ctx, seed01, n_total, i0, n, &w0, &w1, &e2));
+    const u64 pid = (u64)party;
+    return ew_launch(ctx, n, [=] __device__(u64 i) {
+        const ScRand s = sc_rand(w0[i], w1[i]);
+        const u64 rj = party == 0 ? s.r0 : s.r1;
+        const u64 alpha = s.R < s.r0;              // :710
+        const u64 a = (u64)A[i], x = a + rj;       // :718
+        const u64 beta = x < rj;                   // :719
+        const u64 eta2 = (u64)(i64)e2[i];
+        u64 eta = add_L_1((u64)eta1_j[i], pid * eta2);           // :750
+        u64 t = add_L_1((u64)eta1_j[i], (u64)eta1_j[i]) * eta2;  // :751-752
+        eta = sub_L_1(eta, t);                                   // :753
+        const u64 tj = (1 - pid) * (L_1 - 1 - alpha);            // :758
+        u64 theta = add_L_1(beta, tj);                           // :759
+        theta = add_L_1(theta, eta);
+        theta = add_L_1(theta, (u64)delta_j[i]);
+        y_out[i] = (i64)sub_L_1(a, theta); // :765
+    });
+}
+int mpcx_snn_sc_helper_split(mpcx_ctx *ctx, const int64_t *x0, const int64_t *x1, uint64_t n_total, uint64_t i0,
+                             uint64_t n, uint64_t seedS, uint16_t *xbits0, int64_t *delta0, uint16_t *xbits1,
+                             int64_t *delta1) {
+    if (n == 0) return 0;
+    MPCX_REQUIRE(x0 && x1 && xbits0 && delta0 && xbits1 && delta1, "mpcx_snn_sc_helper_split: NULL pointer");
+    MPCX_REQUIRE(i0 + n <= n_total, "mpcx_snn_sc_helper_split: range outside the vector");
+    MPCX_REQUIRE(((uintptr_t)xbits0 & 15) == 0 && ((uintptr_t)xbits1 & 15) == 0, "mpcx_snn_sc_helper_split: xbits must be 16-byte aligned");
+    void *ws;
+    MPCX_TRY(mpcx_ws(ctx, 80 * n, &ws));
+    u64 *x = (u64 *)ws, *d0w = x + n;
+    u8 *rnd = (u8 *)(d0w + n);
+    MPCX_TRY(prg_fill_words(ctx, seedS, 0, 2 * i0, n, 2, (i64 *)d0w, nullptr)); // :848
+    MPCX_TRY(prg_fill_buff_mod67(ctx, seedS, 0, 64 * i0, 64 * n, 0, rnd));       // :838-839
+    const u64 *a = (const u64 *)x0, *b = (const u64 *)x1;
+    MPCX_TRY(ew_launch(ctx, n, [=] __device__(u64 i) {
+        const u64 xv = a[i] + b[i]; // :824
+        const u64 delta = xv < a[i]; // :825
+        x[i] = xv;
+        const u64 D0 = d0w[i] % L_1; // :849
+        delta0[i] = (i64)D0;
+        delta1[i] = (i64)sub_L_1(delta, D0); // :851
+    }));
+    hipLaunchKernelGGL(bit_share_kernel, dim3(grid_for(8 * n)), dim3(256), 0, ctx->stream, (const u64 *)x, (const u64 *)rnd,
+                       n, (uint4 *)xbits0, (uint4 *)xbits1);
+    MPCX_LAUNCH_CHECK();
+    return 0;
+}
+int mpcx_snn_sc_helper_eta(mpcx_ctx *ctx, const int8_t *eta1_plain, uint64_t n_total, uint64_t i0, uint64_t n,
+                           uint64_t seedS, int64_t *eta0, int64_t *eta1) {
+    if (n == 0) return 0;
+    MPCX_REQUIRE(eta1_plain && eta0 && eta1, "mpcx_snn_sc_helper_eta: NULL pointer");
+    MPCX_REQUIRE(i0 + n <= n_total, "mpcx_snn_sc_helper_eta: range outside the vector");
+    void *ws;
+    MPCX_TRY(mpcx_ws(ctx, 8 * n, &ws));
+    u64 *w = (u64 *)ws;
+    MPCX_TRY(prg_fill_words(ctx, seedS, 0, 2 * (n_total + i0), n, 2, (i64 *)w, nullptr)); // :868
+    return ew_launch(ctx, n, [=] __device__(u64 i) {
+        const u64 e0 = w[i] % L_1; // :869
+        eta0[i] = (i64)e0;
+        eta1[i] = (i64)sub_L_1((u64)(i64)eta1_plain[i], e0); // :871
+    });
+}
+
+// ---- msb_L_1
+int mpcx_snn_msbl1_helper_deal(mpcx_ctx *ctx, uint64_t n_total, uint64_t i0, uint64_t n, uint64_t seedS, int64_t *x0,
+                               int64_t *xlsb0, uint16_t *xbits0, int64_t *x1, int64_t *xlsb1, uint16_t *xbits1) {
+    if (n == 0) return 0;
+    MPCX_REQUIRE(x0 && xlsb0 && xbits0 && x1 && xlsb1 && xbits1, "mpcx_snn_msbl1_helper_deal: NULL pointer");
+    MPCX_REQUIRE(i0 + n <= n_total, "mpcx_snn_msbl1_helper_deal: range outside the vector");
+    MPCX_REQUIRE(((uintptr_t)xbits0 & 15) == 0 && ((uintptr_t)xbits1 & 15) == 0, "mpcx_snn_msbl1_helper_deal: xbits must be 16-byte aligned");
+    void *ws;
+    MPCX_TRY(mpcx_ws(ctx, 96 * n, &ws));
+    u64 *w0 = (u64 *)ws, *w1 = w0 + n, *w2 = w1 + n, *xv = w2 + n;
+    u8 *rnd = (u8 *)(xv + n);
+    MPCX_TRY(prg_fill_words(ctx, seedS, 0, 2 * i0, n, 2, (i64 *)w0, nullptr));                  // :911
+    MPCX_TRY(prg_fill_words(ctx, seedS, 0, 2 * (n_total + i0), n, 2, (i64 *)w1, nullptr));     // :913
+    MPCX_TRY(prg_fill_words(ctx, seedS, 0, 2 * (2 * n_total + i0), n, 2, (i64 *)w2, nullptr)); // :917
+    MPCX_TRY(prg_fill_buff_mod67(ctx, seedS, 0, 3 * n_total + 64 * i0, 64 * n, 0, rnd));        // :922-923
+    MPCX_TRY(ew_launch(ctx, n, [=] __device__(u64 i) {
+        const u64 X0 = w0[i] % L_1, X1 = w1[i] % L_1; // :912,:914
+        const u64 X = add_L_1(X0, X1);                // :915
+        xv[i] = X;
+        x0[i] = (i64)X0;
+        x1[i] = (i64)X1;
+        xlsb0[i] = (i64)w2[i];
+        xlsb1[i] = (i64)((X & 1) - w2[i]); // :918
+    }));
+    // :922-926: the random byte is party 1's share, party 0 gets bit + 67 - it
+    hipLaunchKernelGGL(bit_share_kernel, dim3(grid_for(8 * n)), dim3(256), 0, ctx->stream, (const u64 *)xv, (const u64 *)rnd,
+                       n, (uint4 *)xbits1, (uint4 *)xbits0);
+    MPCX_LAUNCH_CHECK();
+    return 0;
+}
+int mpcx_snn_msbl1_helper_beta(mpcx_ctx *ctx, const int8_t *beta1_plain, uint64_t n_total, uint64_t i0, uint64_t n,
+                               uint64_t seedS, int64_t *b0, int64_t *b1) {
+    if (n == 0) return 0;
+    MPCX_REQUIRE(beta1_plain && b0 && b1, "mpcx_snn_msbl1_helper_beta: NULL pointer");
+    MPCX_REQUIRE(i0 + n <= n_total, "mpcx_snn_msbl1_helper_beta: range outside the vector");
+    void *ws;
+    MPCX_TRY(mpcx_ws(ctx, 8 * n, &ws));
+    u64 *w = (u64 *)ws;
+    MPCX_TRY(prg_fill_words(ctx, seedS, 0, 2 * (4 * n_total + i0), n, 2, (i64 *)w, nullptr)); // :953
+    return ew_launch(ctx, n, [=] __device__(u64 i) {
+        b0[i] = (i64)w[i];
+        b1[i] = (i64)((u64)(i64)beta1_plain[i] - w[i]); // :954
+    });
+}
+int mpcx_snn_msbl1_party_open(mpcx_ctx *ctx, const int64_t *A, const int64_t *xj, uint64_t n, int64_t *r_out) {
+    MPCX_REQUIRE((A && xj && r_out) || n == 0, "mpcx_snn_msbl1_party_open: NULL pointer");
+    return ew_launch(ctx, n, [=] __device__(u64 i) {
+        const u64 y = add_L_1((u64)A[i], (u64)A[i]); // :1004
+        r_out[i] = (i64)add_L_1(y, (u64)xj[i]);      // :1005
+    });
+}
+int mpcx_snn_msbl1_party_pc_inputs(mpcx_ctx *ctx, const int64_t *r_own, const int64_t *r_peer, uint64_t i0,
+                                   uint64_t n, uint64_t seed01, int8_t *beta_out, int64_t *R_out) {
+    if (n == 0) return 0;
+    MPCX_REQUIRE(r_own && r_peer && beta_out && R_out, "mpcx_snn_msbl1_party_pc_inputs: NULL pointer");
+    MPCX_TRY(prg_fill_words(ctx, seed01, 0, 2 * i0, n, 2, nullptr, beta_out)); // :985
+    return ew_launch(ctx, n, [=] __device__(u64 i) { R_out[i] = (i64)add_L_1((u64)r_peer[i], (u64)r_own[i]); }); // :1013
+}
+int mpcx_snn_msbl1_party_mid(mpcx_ctx *ctx, int party, const int64_t *beta1_j, const int64_t *xlsb_j,
+                             const int8_t *beta0, const int64_t *R, uint64_t n, int64_t *gamma_out,
+                             int64_t *delta_out) {
+    MPCX_REQUIRE(party == 0 || party == 1, "mpcx_snn_msbl1_party_mid: party %d", party);
+    MPCX_REQUIRE((beta1_j && xlsb_j && beta0 && R && gamma_out && delta_out) || n == 0,
+                 "mpcx_snn_msbl1_party_mid: NULL pointer");
+    const u64 pid = (u64)party;
+    return ew_launch(ctx, n, [=] __device__(u64 i) {
+        const u64 r0 = (u64)R[i] % 2, b0 = (u64)(i64)beta0[i]; // :1025
+        gamma_out[i] = (i64)((u64)beta1_j[i] + pid * b0 - 2 * b0 * (u64)beta1_j[i]); // :1030
+        delta_out[i] = (i64)((u64)xlsb_j[i] + pid * r0 - 2 * r0 * (u64)xlsb_j[i]);   // :1031
+    });
+}
+int mpcx_snn_msbl1_party_finish(mpcx_ctx *ctx, const int64_t *gamma, const int64_t *delta, const int64_t *theta,
+                                uint64_t n, int64_t *B) {
+    MPCX_REQUIRE((gamma && delta && theta && B) || n == 0, "mpcx_snn_msbl1_party_finish: NULL pointer");
+    return ew_launch(ctx, n, [=] __device__(u64 i) {
+        B[i] = (i64)((u64)gamma[i] + (u64)delta[i] - 2 * (u64)theta[i]); // :1036
+    });
+}
+
+} // extern "C"

@@ -1,0 +1,190 @@
+"""GPU parity tests (run with -m gpu on an MI355X): every HIP segment of the ABY3 path, called through
+the C ABI, must reproduce the CPU oracle bit for bit -- per segment, per protocol message and on the
+committed golden checksums."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import protocols as pr
+from oracle_lib import KEY01, KEY12, KEY20, KEYS, cks, prg_pops
+
+pytestmark = pytest.mark.gpu
+
+GOLD = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_goldens.json")))
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    from backends import GpuBackend
+    return GpuBackend()
+
+
+def same_logs(w_gpu, w_orc):
+    assert [t for t, _ in w_gpu.log] == [t for t, _ in w_orc.log]
+    for (tag, a), (_, b) in zip(w_gpu.log, w_orc.log):
+        assert a.dtype == b.dtype and np.array_equal(a, b), f"message {tag} differs"
+
+
+def rnd(rng, n):
+    return rng.integers(-2 ** 63, 2 ** 63, int(n), dtype=np.int64)
+
+
+@pytest.mark.parametrize("seed", [KEYS, KEY01, KEY12, KEY20, 20])
+@pytest.mark.parametrize("first,count", [(0, 1), (0, 257), (255, 2), (256, 256), (1000, 70001), (65535, 131073)])
+def test_prg_pop_parity(gpu, orc, seed, first, count):
+    assert np.array_equal(gpu.prg_fill_pop(seed, first, count), orc.prg_fill_pop(seed, first, count))
+
+
+@pytest.mark.parametrize("first,count", [(0, 1), (0, 160000), (127, 130), (159990, 4000), (1 << 20, 100003)])
+def test_prg_buff_parity(gpu, orc, first, count):
+    gi, gb = gpu.prg_fill_buff(KEY01, first, count)
+    oi, ob = orc.prg_fill_buff(KEY01, first, count)
+    assert np.array_equal(gi, oi) and np.array_equal(gb, ob)
+
+
+def test_prg_nonzero_lcg(gpu, orc):
+    assert np.array_equal(gpu.prg_fill_pop(0x1234567, 3, 5000, lcg=99), orc.prg_fill_pop(0x1234567, 3, 5000, lcg=99))
+
+
+@pytest.mark.parametrize("r,l,c", [(1, 1, 1), (5, 4, 3), (64, 64, 64), (128, 128, 128), (129, 130, 131), (200, 200, 200),
+                                   (3, 1000, 7), (300, 17, 260), (128, 784, 128), (128, 128, 10)])
+@pytest.mark.parametrize("lay", [0, 1])
+def test_ring_gemm_parity(gpu, orc, r, l, c, lay):
+    rng = np.random.default_rng(r * 1000003 + l * 1009 + c)
+    A, B = rnd(rng, r * l), rnd(rng, l * c)
+    want = orc.ring_gemm(A, B, r, l, c, lay, lay, lay)
+    assert np.array_equal(gpu.ring_gemm(A, B, r, l, c, lay, lay, lay), want)
+
+
+def test_ring_gemm_extreme_digits(gpu, orc):
+    """Operands whose signed digits are all -128 / +127 (largest accumulator magnitudes) and K chunking."""
+    r, l, c = 130, 9000, 129  # l > 8192 forces two accumulation chunks
+    for va, vb in ((0x8080808080808080, 0x8080808080808080), (0x7F7F7F7F7F7F7F7F, 0x8080808080808080),
+                   (0xFFFFFFFFFFFFFFFF, 0xFFFFFFFFFFFFFFFF)):
+        A = np.full(r * l, va, dtype=np.uint64).view(np.int64)
+        B = np.full(l * c, vb, dtype=np.uint64).view(np.int64)
+        assert np.array_equal(gpu.ring_gemm(A, B, r, l, c), orc.ring_gemm(A, B, r, l, c))
+
+
+def test_ring_gemm_accumulate_and_mixed_layouts(gpu, orc):
+    r, l, c = 70, 90, 50
+    rng = np.random.default_rng(5)
+    A, B, C0 = rnd(rng, r * l), rnd(rng, l * c), rnd(rng, r * c)
+    for la, lb, lc in ((0, 1, 0), (1, 0, 1), (1, 1, 0)):
+        assert np.array_equal(gpu.ring_gemm(A, B, r, l, c, la, lb, lc, C=C0), orc.ring_gemm(A, B, r, l, c, la, lb, lc, C=C0))
+
+
+def test_relayout(gpu):
+    a = np.arange(37 * 91, dtype=np.int64)
+    assert np.array_equal(gpu.relayout(a, 37, 91, 0, 1), np.ascontiguousarray(a.reshape(37, 91).T).ravel())
+    assert np.array_equal(gpu.relayout(a, 37, 91, 1, 0), np.ascontiguousarray(a.reshape(91, 37).T).ravel())
+
+
+def test_aby3_matmul_config1_golden(gpu, orc):
+    """config 1 (64x64 from PRgenerator(20,0)): shares, messages and revealed product."""
+    n = 64
+    wd = prg_pops(20, 0, 2 * n * n)
+    X, Y = wd[: n * n].copy(), wd[n * n:].copy()
+    wg, wo = pr.World(gpu), pr.World(orc)
+    Zg = pr.aby3_matmul(wg, pr.aby3_share(wg, X, n * n), pr.aby3_share(wg, Y, n * n), n, n, n)
+    Zo = pr.aby3_matmul(wo, pr.aby3_share(wo, X, n * n), pr.aby3_share(wo, Y, n * n), n, n, n)
+    same_logs(wg, wo)
+    g = GOLD["aby3_matmul_64"]
+    assert [cks(Zg[j][0]) for j in range(3)] == g["Z_share0"]
+    assert cks(pr.aby3_reveal(wg, Zg)[0]) == g["Z_plain"]
+    assert [[t, cks(m)] for t, m in wg.log] == g["log"]
+
+
+@pytest.mark.parametrize("r,l,c,layout", [(5, 4, 3, 0), (5, 4, 3, 1), (200, 200, 200, 0), (130, 257, 66, 1)])
+def test_aby3_matmul_protocol_parity(gpu, orc, r, l, c, layout):
+    rng = np.random.default_rng(r + l + c)
+    X, Y = rnd(rng, r * l), rnd(rng, l * c)
+    out = []
+    for be in (gpu, orc):
+        w = pr.World(be)
+        Xs, Ys = pr.aby3_share(w, X, r * l), pr.aby3_share(w, Y, l * c)
+        if layout:
+            cm = lambda S, a, b: [tuple(np.ascontiguousarray(s.reshape(a, b).T).ravel() for s in sh) for sh in S]
+            Xs, Ys = cm(Xs, r, l), cm(Ys, l, c)
+        Zs = pr.aby3_matmul(w, Xs, Ys, r, l, c, layout)
+        out.append((w, pr.aby3_reveal(w, Zs)[0]))
+    same_logs(out[0][0], out[1][0])
+    assert np.array_equal(out[0][1], out[1][1])
+    assert np.array_equal(out[0][1], orc.ring_gemm(X, Y, r, l, c))
+
+
+def test_aby3_matmul_row_blocks_equal_whole(gpu, orc):
+    """Row-block form used for multi-GPU sharding: blocks of Z0 with their mask slices == the whole call."""
+    r, l, c = 96, 40, 72
+    rng = np.random.default_rng(9)
+    X0, X1, Y0, Y1 = rnd(rng, r * l), rnd(rng, r * l), rnd(rng, l * c), rnd(rng, l * c)
+    whole = orc.aby3_matmul_local(X0, X1, Y0, Y1, r, l, c, 0, KEY01, 11, KEY20, 7)
+    parts = []
+    for row0, rows in ((0, 32), (32, 40), (72, 24)):
+        parts.append(gpu.aby3_matmul_local_rows(X0[row0 * l:(row0 + rows) * l], X1[row0 * l:(row0 + rows) * l], Y0, Y1,
+                                                rows, l, c, row0, KEY01, 11, KEY20, 7))
+    assert np.array_equal(np.concatenate(parts), whole)
+
+
+@pytest.mark.parametrize("n", [1, 4, 63, 1000, 4097])
+def test_aby3_relu_chain_parity(gpu, orc, n):
+    """share -> add_prepare -> msb -> bit_inject: every message and every share equals the oracle's."""
+    X = prg_pops(21, 0, n)
+    X[: min(n, 6)] = np.array([0, -1, 1, -2 ** 63, 2 ** 63 - 1, -2], dtype=np.int64)[: min(n, 6)]
+    res = []
+    for be in (gpu, orc):
+        w = pr.World(be)
+        Xs = pr.aby3_share(w, X, n)
+        Gs, Ps = pr.aby3_add_prepare(w, Xs)
+        Zb = pr.aby3_msb(w, Gs, Ps)
+        C = pr.aby3_bit_inject(w, Xs, Zb)
+        res.append((w, Zb, C))
+    same_logs(res[0][0], res[1][0])
+    for j in range(3):
+        for i in range(2):
+            assert np.array_equal(res[0][1][j][i], res[1][1][j][i])
+            assert np.array_equal(res[0][2][j][i], res[1][2][j][i])
+    w = res[0][0]
+    assert np.array_equal(pr.aby3_reveal_bools(w, res[0][1])[0], (X < 0).astype(np.int8))
+    assert np.array_equal(pr.aby3_reveal(w, res[0][2])[0], X * (X < 0))
+    if n == 1000:
+        g = GOLD["aby3_relu_1000"]
+        assert [[t, cks(m)] for t, m in w.log] == g["log"]
+        assert [cks(res[0][2][j][0]) for j in range(3)] == g["C_share0"]
+
+
+def test_aby3_misc_segments_parity(gpu, orc):
+    n = 777
+    rng = np.random.default_rng(2)
+    a, b, c = rnd(rng, n), rnd(rng, n), rnd(rng, n)
+    assert np.array_equal(gpu.aby3_reveal3(a, b, c), orc.aby3_reveal3(a, b, c))
+    ab, bb, cb = [(x & 1).astype(np.int8) for x in (a, b, c)]
+    assert np.array_equal(gpu.aby3_reveal3_bools(ab, bb, cb), orc.aby3_reveal3_bools(ab, bb, cb))
+    assert np.array_equal(gpu.aby3_vecmul_local(a, b, c, a, n, KEY01, 5, KEY20, 9),
+                          orc.aby3_vecmul_local(a, b, c, a, n, KEY01, 5, KEY20, 9))
+    for party in range(3):
+        assert np.array_equal(gpu.aby3_trunc_local(party, a, b, 16, KEY12, 3),
+                              orc.aby3_trunc_local(party, a, b, 16, KEY12, 3))
+    assert np.array_equal(gpu.aby3_share_bools_local(ab, n, KEY01, 1, KEY20, 2),
+                          orc.aby3_share_bools_local(ab, n, KEY01, 1, KEY20, 2))
+    assert np.array_equal(gpu.ring_sar(a, 16), orc.ring_sar(a, 16))
+    assert np.array_equal(gpu.ring_shl1(a), orc.ring_shl1(a))
+    assert np.array_equal(gpu.ring_sub(a, b), orc.ring_sub(a, b))
+
+
+def test_empty_inputs_are_noops(gpu):
+    e = np.zeros(0, dtype=np.int64)
+    assert gpu.ring_add(e, e).size == 0
+    assert gpu.aby3_share_local(None, 0, KEY01, 0, KEY20, 0).size == 0
+    assert gpu.aby3_reveal3(e, e, e).size == 0
+
+
+def test_bad_shapes_are_rejected(gpu):
+    from mpc_amd import MpcxError
+    one = np.zeros(1, dtype=np.int64)
+    with pytest.raises(MpcxError):
+        gpu.ring_gemm(one, one, 0, 1, 1)
+    with pytest.raises(MpcxError):
+        gpu._go("aby3_msb_round_pre", np.zeros(4, np.uint64), 1, 3, ("out", np.int8, 8))
