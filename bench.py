@@ -1,0 +1,278 @@
+#!/usr/bin/env python3
+"""Benchmark of the ABY3 share-matmul hot path on MI355X.
+
+Workload (BASELINE.json configs[1]): ABY3 4096 x 4096 Z_2^64 share matmul + reconstruct.  One step =
+for ALL THREE parties, run on this GPU one after the other with every input already resident in HBM:
+share_matrix(X), share_matrix(Y) (PRG regeneration + mask), matrix_mul's local part (int8-limb MFMA ring
+GEMM of [X0|X1]*[Y0+Y1;Y0] + fused PRG mask) and reveal_matrix's sum.  Party-to-party messages are
+device buffers handed over by pointer (the messenger round is not part of the hot path).
+
+--gpus N (launched by torch.distributed.run, one rank per GPU): weak scaling over matmul row-blocks --
+X has 4096*N rows, rank g owns rows [4096 g, 4096 (g+1)), Y is replicated, and the row-blocks of each
+party's Z0 (the message to the previous party) are gathered with one RCCL all-gather per party.
+
+value = ring operations of the reference's formulation (3 products, 2 ops per multiply-add:
+3 parties x 3*2*r*l*c) per second, whole job.  Extra keys report the privateCompare / MSB element rates,
+the roofline of the dominant kernel and the CPU oracle timed on the host cores."""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+KEY01, KEY12, KEY20, KEYS = 0xAB01, 0xBC12, 0xCA20, 0xF0
+INT8_PEAK_TOPS = 5033.0  # 256 CU x 4 SIMD x 2048 int8 op/clk x 2.4 GHz (2x the 2.5 PF bf16 dense peak)
+HBM_PEAK_GBS = 8000.0
+
+
+def pair_seed(a, b):
+    return {frozenset((0, 1)): KEY01, frozenset((1, 2)): KEY12, frozenset((0, 2)): KEY20}[frozenset((a, b))]
+
+
+def prof_read(ctx, name):
+    ms, cnt = ctypes.c_double(), ctypes.c_uint64()
+    ctx._call("mpcx_profile_read", name.encode(), ctypes.byref(ms), ctypes.byref(cnt))
+    return ms.value, cnt.value
+
+
+class Aby3MatmulJob:
+    def __init__(self, ctx, torch, dev, n, rank, world):
+        self.ctx, self.torch, self.n, self.rank, self.world = ctx, torch, n, rank, world
+        self.rows, self.l, self.c = n, n, n
+        self.rows_total = n * world
+        self.row0 = rank * n
+        i64 = torch.int64
+        e = lambda k: torch.empty(k, dtype=i64, device=dev)
+        # plaintext inputs: X then Y row-major from PRgenerator(20,0).pop_int64()
+        self.X, self.Y = e(self.rows * self.l), e(self.l * self.c)
+        ctx.call("prg_fill_pop", 20, 0, self.row0 * self.l, self.rows * self.l, self.X)
+        ctx.call("prg_fill_pop", 20, 0, self.rows_total * self.l, self.l * self.c, self.Y)
+        self.RX = [e(self.rows * self.l) for _ in range(3)]
+        self.RY = [e(self.l * self.c) for _ in range(3)]
+        self.Z0 = [e(self.rows * self.c) for _ in range(3)]
+        self.Zfull = [e(self.rows_total * self.c) for _ in range(3)] if world > 1 else None
+        self.Zplain = [e(self.rows * self.c) for _ in range(3)]
+        # pop-stream checkpoints for everything a step consumes (fresh engines every step)
+        pops = self.rows_total * self.l + self.l * self.c + self.rows_total * self.c
+        for k in (KEY01, KEY12, KEY20):
+            ctx.call("prg_ckpt_build", k, 0, pops, 0)
+        ctx.call("prg_ckpt_build", 20, 0, self.rows_total * self.l + self.l * self.c, 0)
+        ctx.sync()
+
+    def step(self):
+        ctx, n2x, n2y = self.ctx, self.rows_total * self.l, self.l * self.c
+        for j in range(3):
+            nx, pv = (j + 1) % 3, (j + 2) % 3
+            sn, sp = pair_seed(j, nx), pair_seed(j, pv)
+            off = self.row0 * self.l
+            ctx.call("aby3_share_local", self.X if j == 0 else None, self.rows * self.l, sn, off, sp, off, self.RX[j])
+            ctx.call("aby3_share_local", self.Y if j == 0 else None, n2y, sn, n2x, sp, n2x, self.RY[j])
+        for j in range(3):
+            nx, pv = (j + 1) % 3, (j + 2) % 3
+            sn, sp = pair_seed(j, nx), pair_seed(j, pv)
+            ctx.call("aby3_matmul_local_rows", self.RX[j], self.RX[nx], self.RY[j], self.RY[nx], self.rows, self.l,
+                     self.c, self.row0, sn, n2x + n2y, sp, n2x + n2y, self.Z0[j])
+        if self.world > 1:
+            import torch.distributed as dist
+            for j in range(3):  # the message party j hands to the messenger: all row-blocks of Z0
+                dist.all_gather_into_tensor(self.Zfull[j], self.Z0[j])
+        for j in range(3):
+            ctx.call("aby3_reveal3", self.Z0[(j + 2) % 3], self.Z0[j], self.Z0[(j + 1) % 3], self.Zplain[j],
+                     self.rows * self.c)
+
+    def ring_ops_per_step(self):
+        return 3 * 3 * 2 * self.rows_total * self.l * self.c
+
+    def verify(self):
+        """All parties reveal the same Z, and sampled entries equal the exact big-integer dot products."""
+        t = self.torch
+        assert t.equal(self.Zplain[0], self.Zplain[1]) and t.equal(self.Zplain[1], self.Zplain[2])
+        X = self.X.view(self.rows, self.l).cpu().numpy().view(np.uint64)
+        Y = self.Y.view(self.l, self.c).cpu().numpy().view(np.uint64)
+        Z = self.Zplain[0].view(self.rows, self.c).cpu().numpy().view(np.uint64)
+        rng = np.random.default_rng(1)
+        for _ in range(24):
+            i, k = int(rng.integers(self.rows)), int(rng.integers(self.c))
+            want = sum(int(a) * int(b) for a, b in zip(X[i], Y[:, k])) % (1 << 64)
+            assert int(Z[i, k]) == want, f"Z[{i},{k}] wrong"
+
+
+def cpu_baseline(n=1024):
+    """The CPU oracle (a port of the reference algorithm) on the same workload at a bounded size: three
+    party threads, each single-threaded, as the reference runs three single-threaded processes."""
+    from backends import OracleBackend
+    from oracle_lib import prg_pops
+    orc = OracleBackend()
+    wd = prg_pops(20, 0, 2 * n * n)
+    X, Y = wd[: n * n].copy(), wd[n * n:].copy()
+    R = {}
+
+    def share(j):
+        nx, pv = (j + 1) % 3, (j + 2) % 3
+        sn, sp = pair_seed(j, nx), pair_seed(j, pv)
+        R[("x", j)] = orc.aby3_share_local(X if j == 0 else None, n * n, sn, 0, sp, 0)
+        R[("y", j)] = orc.aby3_share_local(Y if j == 0 else None, n * n, sn, n * n, sp, n * n)
+
+    def mul(j):
+        nx, pv = (j + 1) % 3, (j + 2) % 3
+        sn, sp = pair_seed(j, nx), pair_seed(j, pv)
+        R[("z", j)] = orc.aby3_matmul_local(R[("x", j)], R[("x", nx)], R[("y", j)], R[("y", nx)], n, n, n, 0, sn,
+                                            2 * n * n, sp, 2 * n * n)
+
+    def rev(j):
+        R[("p", j)] = orc.aby3_reveal3(R[("z", (j + 2) % 3)], R[("z", j)], R[("z", (j + 1) % 3)])
+
+    def phase(fn):
+        th = [threading.Thread(target=fn, args=(j,)) for j in range(3)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+
+    orc.prg_fill_pop(KEY01, 0, 3 * n * n), orc.prg_fill_pop(KEY12, 0, 3 * n * n), orc.prg_fill_pop(KEY20, 0, 3 * n * n)
+    t0 = time.perf_counter()
+    phase(share)
+    phase(mul)
+    phase(rev)
+    dt = time.perf_counter() - t0
+    return {"value": 3 * 6 * n ** 3 / dt / 1e9, "unit": "Gop/s", "cores": 3, "kind": "port",
+            "sample": f"ABY3 {n}x{n} share_matrix x2 + matrix_mul + reveal_matrix, 3 party threads, {dt:.2f} s wall"}
+
+
+def bitwise_rates(ctx, torch, dev, log2n_pc=24, log2n_msb=22):
+    """Secondary metric: privateCompare (party and helper role) and the ABY3 msb rounds, elements / s."""
+    out = {}
+    n = 1 << log2n_pc
+    t0 = time.perf_counter()
+    ctx.call("prg_ckpt_build", KEY01, 0, 0, 128 * n)
+    out["pc_ckpt_build_s"] = round(time.perf_counter() - t0, 2)
+    xb = torch.randint(0, 67, (64 * n,), dtype=torch.int16, device=dev)
+    beta = torch.randint(0, 2, (n,), dtype=torch.int8, device=dev)
+    r = torch.randint(-2 ** 62, 2 ** 62, (n,), dtype=torch.int64, device=dev)
+    d0 = torch.empty(64 * n, dtype=torch.int16, device=dev)
+    d1 = torch.empty(64 * n, dtype=torch.int16, device=dev)
+    b2 = torch.empty(n, dtype=torch.int8, device=dev)
+    ctx.call("snn_pc_party", 0, xb, beta, r, n, 0, n, KEY01, d0)
+    ctx.call("snn_pc_party", 1, xb, beta, r, n, 0, n, KEY01, d1)
+    ctx.call("snn_pc_helper", d0, d1, n, b2)
+    ctx.sync()
+    ctx.call("profile", 1)
+    reps = 3
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ctx.call("snn_pc_party", 0, xb, beta, r, n, 0, n, KEY01, d0)
+    ctx.sync()
+    dt = (time.perf_counter() - t0) / reps
+    out["pc_party_elems_per_s"] = n / dt
+    ms, cnt = prof_read(ctx, "pc_party")
+    out["pc_party_kernel_GBps"] = 265.0 * n / (ms / cnt * 1e-3) / 1e9
+    msp, cntp = prof_read(ctx, "prg_fill")
+    out["pc_party_prg_ms"] = msp / reps
+    out["pc_party_kernel_ms"] = ms / cnt
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ctx.call("snn_pc_helper", d0, d1, n, b2)
+    ctx.sync()
+    dt = (time.perf_counter() - t0) / reps
+    out["pc_helper_elems_per_s"] = n / dt
+    out["pc_helper_GBps"] = 257.0 * n / dt / 1e9
+    ctx.call("profile", 0)
+    del xb, d0, d1
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--n", type=int, default=4096)
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-bitwise", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from mpc_amd import Context
+    ctx = Context(local_rank)
+    ctx.call("set_stream", torch.cuda.current_stream().cuda_stream)
+
+    job = Aby3MatmulJob(ctx, torch, dev, args.n, rank, world)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        job.step()
+    barrier()
+    ctx.call("profile", 1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        job.step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    gemm_ms, gemm_cnt = prof_read(ctx, "limb_gemm")
+    breakdown = {k: round(prof_read(ctx, k)[0] / args.steps, 3) for k in ("limb_gemm", "split_limbs", "combine", "prg_fill")}
+    ctx.call("profile", 0)
+    job.verify()
+
+    if rank == 0:
+        value = job.ring_ops_per_step() * args.steps / dt / 1e9
+        # dominant kernel: the int8-limb MFMA GEMM.  Algorithmic work per launch: 36 limb pairs x 2 ops x
+        # rows x c x K with K = 2l (the two ring products X0*(Y0+Y1) and X1*Y0 concatenated along K)
+        ops_per_launch = 36 * 2 * job.rows * job.c * (2 * job.l)
+        avg_s = gemm_ms / gemm_cnt * 1e-3
+        achieved = ops_per_launch / avg_s / 1e12
+        res = {
+            "metric": "Z_2^64 share-matmul Gop/s + MSB/privateCompare elems/sec at 1/2/4/8 GPUs",
+            "value": value, "unit": "Gop/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u64 ring via int8 limbs (int32 accumulate)", "data": "synthetic",
+            "config": {"workload": f"ABY3 {job.rows_total}x{job.l} . {job.l}x{job.c} Z_2^64 share matmul + reconstruct, "
+                                   "3 parties per step (share_matrix x2, matrix_mul local, reveal_matrix), "
+                                   "inputs from PRgenerator(20,0)",
+                       "rows_per_gpu": job.rows, "parallelism": f"row-block x{world}" if world > 1 else "single GPU"},
+            "roofline": {"bound": "mfma", "kernel": "limb_gemm_kernel", "achieved": achieved, "peak": INT8_PEAK_TOPS,
+                         "unit": "TFLOP/s", "frac": achieved / INT8_PEAK_TOPS, "traffic": None,
+                         "avg_launch_ms": avg_s * 1e3, "launches": gemm_cnt,
+                         "note": "int8 TOP/s: 36 limb pairs x 2 x rows x c x 2l per launch"},
+            "kernel_ms_per_step": breakdown,
+        }
+        if world == 1 and not args.no_bitwise:
+            try:
+                res["bitwise"] = bitwise_rates(ctx, torch, dev)
+            except Exception as ex:  # secondary metric must not hide the headline number
+                res["bitwise"] = {"error": str(ex)}
+        if world == 1 and not args.no_cpu:
+            res["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

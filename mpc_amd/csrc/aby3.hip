@@ -300,6 +300,7 @@ int mpcx_aby3_msb_round_pre(mpcx_ctx *ctx, uint64_t *state, uint64_t n, uint64_t
     MPCX_REQUIRE(temp == 32 || temp == 16 || temp == 8 || temp == 4 || temp == 2 || temp == 1,
                  "mpcx_aby3_msb_round_pre: temp must be one of 32,16,8,4,2,1");
     MPCX_REQUIRE(((uintptr_t)msg_out & 7) == 0, "mpcx_aby3_msb_round_pre: msg_out must be 8-byte aligned");
+    ProfScope ps(ctx, PROF_MSB);
     if (temp >= 4)
         hipLaunchKernelGGL(msb_round_pre_wide, dim3(grid_for(n * (temp / 4))), dim3(256), 0, ctx->stream, state, n,
                            (u32)temp, (u64 *)msg_out);
@@ -315,6 +316,7 @@ int mpcx_aby3_msb_round_post(mpcx_ctx *ctx, uint64_t *state, uint64_t n, uint64_
     MPCX_REQUIRE(temp == 32 || temp == 16 || temp == 8 || temp == 4 || temp == 2 || temp == 1,
                  "mpcx_aby3_msb_round_post: temp must be one of 32,16,8,4,2,1");
     MPCX_REQUIRE(((uintptr_t)msg_in & 7) == 0, "mpcx_aby3_msb_round_post: msg_in must be 8-byte aligned");
+    ProfScope ps(ctx, PROF_MSB);
     if (temp >= 4)
         hipLaunchKernelGGL(msb_round_post_wide, dim3(grid_for(n * (temp / 4))), dim3(256), 0, ctx->stream, state, n,
                            (u32)temp, (const u64 *)msg_in);

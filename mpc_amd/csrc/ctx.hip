@@ -71,6 +71,11 @@ int mpcx_shutdown(mpcx_ctx *ctx) {
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
     if (ctx->ws) hipFree(ctx->ws);
+    for (auto &v : ctx->prof_ev)
+        for (auto &p : v) {
+            (void)hipEventDestroy(p.first);
+            (void)hipEventDestroy(p.second);
+        }
     if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
     return 0;
@@ -121,6 +126,38 @@ int mpcx_d2d(mpcx_ctx *ctx, void *dst, const void *src, uint64_t bytes) {
     MPCX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
     return 0;
 }
+static const char *kProfNames[PROF_SLOTS] = {"limb_gemm", "split_limbs", "combine", "prg_fill", "pc_party", "pc_helper", "msb_round"};
+
+int mpcx_profile(mpcx_ctx *ctx, int enable) {
+    MPCX_HIP(hipStreamSynchronize(ctx->stream));
+    for (auto &v : ctx->prof_ev) {
+        for (auto &p : v) {
+            (void)hipEventDestroy(p.first);
+            (void)hipEventDestroy(p.second);
+        }
+        v.clear();
+    }
+    ctx->prof = enable != 0;
+    return 0;
+}
+int mpcx_profile_read(mpcx_ctx *ctx, const char *kernel, double *total_ms, uint64_t *launches) {
+    MPCX_REQUIRE(kernel && total_ms && launches, "mpcx_profile_read: NULL pointer");
+    MPCX_HIP(hipStreamSynchronize(ctx->stream));
+    for (int s = 0; s < PROF_SLOTS; s++) {
+        if (std::string(kernel) != kProfNames[s]) continue;
+        double tot = 0;
+        for (auto &p : ctx->prof_ev[s]) {
+            float ms = 0;
+            MPCX_HIP(hipEventElapsedTime(&ms, p.first, p.second));
+            tot += ms;
+        }
+        *total_ms = tot;
+        *launches = ctx->prof_ev[s].size();
+        return 0;
+    }
+    return mpcx_fail(ctx, "mpcx_profile_read: unknown kernel name '%s'", kernel);
+}
+
 int mpcx_reserve_workspace(mpcx_ctx *ctx, uint64_t bytes) {
     void *p;
     return mpcx_ws(ctx, bytes, &p);

@@ -4,6 +4,8 @@
 #include <cstdint>
 #include <cstdio>
 #include <string>
+#include <utility>
+#include <vector>
 
 #include "../../include/mpcx.h"
 
@@ -23,7 +25,12 @@ struct PrgCk {
 constexpr u64 PRG_CK = 256;        // stream words per checkpoint
 constexpr u64 PRG_POP_T0 = 320000; // stream word of the first pop (2 * BUFF_NUM, utils/PRgenerator.hpp:6)
 
+// optional per-kernel timing with HIP events on the context's stream (mpcx_profile / mpcx_profile_read)
+enum ProfSlotId { PROF_GEMM = 0, PROF_SPLIT, PROF_COMBINE, PROF_PRG, PROF_PC_PARTY, PROF_PC_HELPER, PROF_MSB, PROF_SLOTS };
+
 struct mpcx_ctx {
+    bool prof = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev[PROF_SLOTS];
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -53,6 +60,26 @@ int mpcx_prg_table(mpcx_ctx *ctx, u64 seed, u64 lcg, u64 t_end, const PrgCk **de
         if (!(cond)) return mpcx_fail(ctx, __VA_ARGS__);                                                               \
     } while (0)
 #define MPCX_LAUNCH_CHECK() MPCX_HIP(hipGetLastError())
+
+// records a start/stop event pair around the launches issued during its lifetime (no-op unless profiling)
+struct ProfScope {
+    mpcx_ctx *ctx;
+    int slot;
+    hipEvent_t stop = nullptr;
+    ProfScope(mpcx_ctx *c, int s) : ctx(c), slot(s) {
+        if (!ctx->prof) return;
+        hipEvent_t start;
+        if (hipEventCreate(&start) != hipSuccess || hipEventCreate(&stop) != hipSuccess) {
+            stop = nullptr;
+            return;
+        }
+        (void)hipEventRecord(start, ctx->stream);
+        ctx->prof_ev[slot].push_back({start, stop});
+    }
+    ~ProfScope() {
+        if (stop) (void)hipEventRecord(stop, ctx->stream);
+    }
+};
 
 // internal launchers used across translation units (all asynchronous on ctx->stream)
 int prg_fill_words(mpcx_ctx *ctx, u64 seed, u64 lcg, u64 t_first, u64 count, u64 stride, i64 *out, i8 *bools);

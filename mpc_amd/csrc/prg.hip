@@ -138,6 +138,7 @@ static int prg_launch(mpcx_ctx *ctx, u64 seed, u64 lcg, u64 t_first, u64 t_end, 
     const u64 nseg = seg1 - seg0 + 1;
     const u64 grid = ceil_div(nseg, 256);
     MPCX_REQUIRE(grid < (1ull << 31), "prg fill: range too large for one launch");
+    ProfScope ps(ctx, PROF_PRG);
     hipLaunchKernelGGL(prg_fill_kernel, dim3((u32)grid), dim3(256), 0, ctx->stream, ck, seg0, nseg, t_first, t_end, mode,
                        out64, out8);
     MPCX_LAUNCH_CHECK();

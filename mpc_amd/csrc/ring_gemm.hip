@@ -222,6 +222,7 @@ int ring_gemm_parts(mpcx_ctx *ctx, const GemmPart *parts, int nparts, u64 r, u64
     for (u64 kb = 0; kb < l; kb += lc) {
         const u64 klen = (l - kb < lc) ? l - kb : lc;
         for (int p = 0; p < nparts; p++) {
+            ProfScope ps(ctx, PROF_SPLIT);
             const u64 *a = (const u64 *)parts[p].A + kb * skA;
             const u64 *b = (const u64 *)parts[p].B + kb * skB;
             const u64 *b2 = parts[p].Bplus ? (const u64 *)parts[p].Bplus + kb * skB : nullptr;
@@ -230,11 +231,15 @@ int ring_gemm_parts(mpcx_ctx *ctx, const GemmPart *parts, int nparts, u64 r, u64
             hipLaunchKernelGGL(split_limbs_kernel, dim3((u32)(lc / 64), (u32)(Np / 64)), dim3(256), 0, ctx->stream, b,
                                b2, c, klen, soB, skB, Bpl, Np, Kp, (u64)p * lc);
         }
-        hipLaunchKernelGGL(limb_gemm_kernel, dim3(tiles_m * tiles_n), dim3(256), 0, ctx->stream, Apl, Bpl, Cpl, (u32)Mp,
-                           (u32)Np, (u32)Kp, tiles_m, tiles_n);
+        {
+            ProfScope ps(ctx, PROF_GEMM);
+            hipLaunchKernelGGL(limb_gemm_kernel, dim3(tiles_m * tiles_n), dim3(256), 0, ctx->stream, Apl, Bpl, Cpl,
+                               (u32)Mp, (u32)Np, (u32)Kp, tiles_m, tiles_n);
+        }
         const u64 total = r * c;
         const u32 grid = (u32)(ceil_div(total, 256) < 4096 ? ceil_div(total, 256) : 4096);
         const bool last = kb + lc >= l;
+        ProfScope pc(ctx, PROF_COMBINE);
         hipLaunchKernelGGL(combine_kernel, dim3(grid), dim3(256), 0, ctx->stream, Cpl, Mp, Np, r, c,
                            last ? (const u64 *)add : nullptr, last ? (const u64 *)sub : nullptr, (u64 *)Z,
                            layZ ? (u64)1 : c, layZ ? r : (u64)1, (accumulate || !first) ? 1 : 0);

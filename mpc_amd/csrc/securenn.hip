@@ -324,6 +324,7 @@ int mpcx_snn_pc_party(mpcx_ctx *ctx, int party, const uint16_t *xbits, const int
     u8 *S = (u8 *)ws, *U = S + 64 * n;
     MPCX_TRY(prg_fill_buff_mod67(ctx, seed01, 0, 64 * i0, 64 * n, 1, S));                // :523,525-529
     MPCX_TRY(prg_fill_buff_mod67(ctx, seed01, 0, 64 * n_total + 64 * i0, 64 * n, 1, U)); // :524,530-534
+    ProfScope ps(ctx, PROF_PC_PARTY);
     hipLaunchKernelGGL(pc_party_kernel, dim3(grid_for(8 * n)), dim3(256), 0, ctx->stream, party, (const uint4 *)xbits, beta,
                        r, (const u64 *)S, (const u64 *)U, n, (uint4 *)d_out);
     MPCX_LAUNCH_CHECK();
@@ -333,6 +334,7 @@ int mpcx_snn_pc_helper(mpcx_ctx *ctx, const uint16_t *d0, const uint16_t *d1, ui
     if (n == 0) return 0;
     MPCX_REQUIRE(d0 && d1 && beta_out, "mpcx_snn_pc_helper: NULL pointer");
     MPCX_REQUIRE(((uintptr_t)d0 & 15) == 0 && ((uintptr_t)d1 & 15) == 0, "mpcx_snn_pc_helper: d0/d1 must be 16-byte aligned");
+    ProfScope ps(ctx, PROF_PC_HELPER);
     hipLaunchKernelGGL(pc_helper_kernel, dim3(grid_for(8 * n)), dim3(256), 0, ctx->stream, (const uint4 *)d0,
                        (const uint4 *)d1, n, beta_out);
     MPCX_LAUNCH_CHECK();
