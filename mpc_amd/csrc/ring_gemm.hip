@@ -144,6 +144,137 @@ __global__ __launch_bounds__(256) void limb_gemm_kernel(const i8 *__restrict__ A
     }
 }
 
+// ---------------------------------------------------------------- gemm, large tiles
+// Same contraction on a 256x256 block tile: 8 waves as 2(M) x 4(N), each 128x64 = 4x2 MFMA tiles.
+// K is walked as ONE flat sequence of 128-byte steps over the 36 (A plane i, B plane s-i) pairs; the
+// accumulators are flushed to plane s whenever s changes.  Operand tiles go global -> LDS with
+// global_load_lds (16 B per lane, no VGPR staging) into two 64 KiB buffers: the loads of step t+1 are
+// in flight while step t is multiplied.  An LDS-DMA wave-instruction writes 1 KiB linearly (8 rows of
+// 128 B), so the bank swizzle is applied to the per-lane SOURCE address and undone on the ds_read:
+// 16-byte chunk c of row r lives at chunk position c ^ ((r >> 1) & 7), which puts the 16 rows a
+// ds_read_b128 lane group touches on 16 different 16-byte bank slots.
+constexpr u32 TM = 256, TN = 256, TK = 128;
+__global__ __launch_bounds__(512) void limb_gemm256_kernel(const i8 *__restrict__ Apl, const i8 *__restrict__ Bpl,
+                                                           i32 *__restrict__ Cpl, u32 Mp, u32 Np, u32 Kp, u32 tiles_m,
+                                                           u32 tiles_n) {
+    __shared__ __attribute__((aligned(1024))) i8 lds[2 * (TM + TN) * TK]; // 128 KiB
+    const u32 tid = threadIdx.x, lane = tid & 63;
+    const u32 wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const u32 wm = wid >> 2, wn = wid & 3, lr = lane & 31, lh = lane >> 5;
+
+    const u32 nwg = tiles_m * tiles_n;
+    const u32 bid = blockIdx.x;
+    const u32 qq = nwg / 8, rem = nwg % 8, xcd = bid % 8;
+    const u32 swz = (xcd < rem ? xcd * (qq + 1) : rem * (qq + 1) + (xcd - rem) * qq) + bid / 8;
+    const u32 tm = swz / tiles_n, tn = swz % tiles_n;
+
+    const u64 strideA = (u64)Mp * Kp, strideB = (u64)Np * Kp, strideC = (u64)Mp * Np;
+    const i8 *Ablk = Apl + (u64)tm * TM * Kp;
+    const i8 *Bblk = Bpl + (u64)tn * TN * Kp;
+
+    // staging: wave w issues 4 A pieces and 4 B pieces per step; piece p = 4w+q covers rows 8p..8p+7
+    u32 goff[4];
+#pragma unroll
+    for (u32 q = 0; q < 4; q++) {
+        const u32 row = (wid * 4 + q) * 8 + (lane >> 3);
+        const u32 ch = (lane & 7) ^ ((row >> 1) & 7);
+        goff[q] = row * Kp + ch * 16;
+    }
+    // fragment reads: row (within the wave's 128 / 64 rows) lr + 32*tile; the swizzle term only depends on lr
+    const u32 rsw = (lr >> 1) & 7;
+    const u32 a_row_off = (wm * 128 + lr) * TK, b_row_off = (wn * 64 + lr) * TK;
+
+    const u32 nk = Kp / TK;
+    const u32 T = 36 * nk;
+
+    auto stage = [&](u32 buf, u32 pi, u32 pj, u32 kt) {
+        const i8 *Ap = Ablk + pi * strideA + kt * TK;
+        const i8 *Bp = Bblk + pj * strideB + kt * TK;
+        i8 *la = lds + buf * ((TM + TN) * TK) + wid * 4096;
+        i8 *lb = la + TM * TK;
+#pragma unroll
+        for (u32 q = 0; q < 4; q++) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(Ap + goff[q]),
+                                             (__attribute__((address_space(3))) void *)(la + q * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(Bp + goff[q]),
+                                             (__attribute__((address_space(3))) void *)(lb + q * 1024), 16, 0, 0);
+        }
+    };
+
+    v16i acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[a][b][r] = 0;
+
+    u32 ps = 0, pi = 0, pkt = 0; // tile being prefetched
+    u32 cs = 0, ci = 0, ckt = 0; // tile being multiplied
+    stage(0, 0, 0, 0);
+    __syncthreads();
+    u32 cur = 0;
+    for (u32 t = 0; t < T; t++) {
+        if (t + 1 < T) {
+            if (++pkt == nk) {
+                pkt = 0;
+                if (pi == ps) {
+                    ps++;
+                    pi = 0;
+                } else {
+                    pi++;
+                }
+            }
+            stage(cur ^ 1, pi, ps - pi, pkt);
+        }
+        const i8 *la = lds + cur * ((TM + TN) * TK);
+        const i8 *lb = la + TM * TK;
+#pragma unroll
+        for (u32 kk = 0; kk < TK / 32; kk++) {
+            const u32 coff = ((2 * kk + lh) ^ rsw) << 4;
+            v4i a[4], b[2];
+#pragma unroll
+            for (u32 mi = 0; mi < 4; mi++) a[mi] = *(const v4i *)(la + a_row_off + mi * 32 * TK + coff);
+#pragma unroll
+            for (u32 ni = 0; ni < 2; ni++) b[ni] = *(const v4i *)(lb + b_row_off + ni * 32 * TK + coff);
+#pragma unroll
+            for (u32 mi = 0; mi < 4; mi++)
+#pragma unroll
+                for (u32 ni = 0; ni < 2; ni++)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+        }
+        // last step of this s: flush the accumulators to plane s
+        const bool last_k = (ckt + 1 == nk);
+        if (last_k && ci == cs) {
+            i32 *Cs = Cpl + cs * strideC;
+#pragma unroll
+            for (u32 mi = 0; mi < 4; mi++)
+#pragma unroll
+                for (u32 ni = 0; ni < 2; ni++)
+#pragma unroll
+                    for (u32 r = 0; r < 16; r++) {
+                        const u32 row = tm * TM + wm * 128 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        const u32 col = tn * TN + wn * 64 + ni * 32 + lr;
+                        Cs[(u64)row * Np + col] = acc[mi][ni][r];
+                        acc[mi][ni][r] = 0;
+                    }
+        }
+        if (last_k) {
+            ckt = 0;
+            if (ci == cs) {
+                cs++;
+                ci = 0;
+            } else {
+                ci++;
+            }
+        } else {
+            ckt++;
+        }
+        __syncthreads(); // drains this step's LDS-DMA (vmcnt) and the fragment reads before the buffers swap
+        cur ^= 1;
+    }
+}
+
 // ---------------------------------------------------------------- combine
 // Z[m][n] (+)= sum_s (int64)Cpl[s][m][n] << 8s  (+ add[idx] - sub[idx]), idx = m*N + n (row-major)
 __global__ __launch_bounds__(256) void combine_kernel(const i32 *__restrict__ Cpl, u64 Mp, u64 Np, u64 M, u64 N,
@@ -193,8 +324,12 @@ static u64 part_chunk_len(int nparts, u64 l) {
     while ((u64)nparts * lc > max_kc && lc > BK) lc = round_up(lc / 2, BK);
     return lc;
 }
+// block tile edge: the 256-square LDS-DMA kernel for large outputs, the 128-square one otherwise
+static u64 tile_edge(u64 r, u64 c) { return (r >= 512 && c >= 512) ? TM : BM; }
+
 u64 ring_gemm_ws_bytes(int nparts, u64 r, u64 l, u64 c) {
-    const u64 Mp = round_up(r, BM), Np = round_up(c, BN), Kp = (u64)nparts * part_chunk_len(nparts, l);
+    const u64 te = tile_edge(r, c);
+    const u64 Mp = round_up(r, te), Np = round_up(c, te), Kp = (u64)nparts * part_chunk_len(nparts, l);
     const u64 bytesA = 8 * Mp * Kp, bytesB = 8 * Np * Kp, bytesC = 8 * Mp * Np * 4;
     return ((bytesA + 255) & ~255ull) + ((bytesB + 255) & ~255ull) + ((bytesC + 255) & ~255ull);
 }
@@ -205,7 +340,8 @@ int ring_gemm_parts(mpcx_ctx *ctx, const GemmPart *parts, int nparts, u64 r, u64
                  (unsigned long long)l, (unsigned long long)c);
     MPCX_REQUIRE(r < (1u << 30) && c < (1u << 30) && l < (1u << 30), "ring gemm: dimension too large");
     MPCX_REQUIRE(nparts >= 1 && nparts <= 8, "ring gemm: bad part count");
-    const u64 Mp = round_up(r, BM), Np = round_up(c, BN);
+    const u64 te = tile_edge(r, c);
+    const u64 Mp = round_up(r, te), Np = round_up(c, te);
     const u64 lc = part_chunk_len(nparts, l); // per-part chunk length along l
     const u64 Kp = (u64)nparts * lc;
     MPCX_REQUIRE(Kp <= 8192, "ring gemm: cannot chunk K");
@@ -215,7 +351,7 @@ int ring_gemm_parts(mpcx_ctx *ctx, const GemmPart *parts, int nparts, u64 r, u64
     i8 *Apl = (i8 *)ws;
     i8 *Bpl = Apl + ((bytesA + 255) & ~255ull);
     i32 *Cpl = (i32 *)(Bpl + ((bytesB + 255) & ~255ull));
-    const u32 tiles_m = (u32)(Mp / BM), tiles_n = (u32)(Np / BN);
+    const u32 tiles_m = (u32)(Mp / te), tiles_n = (u32)(Np / te);
     const u64 soA = layA ? 1 : l, skA = layA ? r : 1; // A(o=row, k)
     const u64 soB = layB ? l : 1, skB = layB ? 1 : c; // B(o=col, k)
     int first = 1;
@@ -233,8 +369,12 @@ int ring_gemm_parts(mpcx_ctx *ctx, const GemmPart *parts, int nparts, u64 r, u64
         }
         {
             ProfScope ps(ctx, PROF_GEMM);
-            hipLaunchKernelGGL(limb_gemm_kernel, dim3(tiles_m * tiles_n), dim3(256), 0, ctx->stream, Apl, Bpl, Cpl,
-                               (u32)Mp, (u32)Np, (u32)Kp, tiles_m, tiles_n);
+            if (te == TM)
+                hipLaunchKernelGGL(limb_gemm256_kernel, dim3(tiles_m * tiles_n), dim3(512), 0, ctx->stream, Apl, Bpl,
+                                   Cpl, (u32)Mp, (u32)Np, (u32)Kp, tiles_m, tiles_n);
+            else
+                hipLaunchKernelGGL(limb_gemm_kernel, dim3(tiles_m * tiles_n), dim3(256), 0, ctx->stream, Apl, Bpl, Cpl,
+                                   (u32)Mp, (u32)Np, (u32)Kp, tiles_m, tiles_n);
         }
         const u64 total = r * c;
         const u32 grid = (u32)(ceil_div(total, 256) < 4096 ? ceil_div(total, 256) : 4096);

@@ -49,7 +49,8 @@ def test_prg_nonzero_lcg(gpu, orc):
 
 
 @pytest.mark.parametrize("r,l,c", [(1, 1, 1), (5, 4, 3), (64, 64, 64), (128, 128, 128), (129, 130, 131), (200, 200, 200),
-                                   (3, 1000, 7), (300, 17, 260), (128, 784, 128), (128, 128, 10)])
+                                   (3, 1000, 7), (300, 17, 260), (128, 784, 128), (128, 128, 10),
+                                   (512, 256, 512), (600, 130, 520), (1024, 64, 768)])
 @pytest.mark.parametrize("lay", [0, 1])
 def test_ring_gemm_parity(gpu, orc, r, l, c, lay):
     rng = np.random.default_rng(r * 1000003 + l * 1009 + c)
@@ -97,7 +98,8 @@ def test_aby3_matmul_config1_golden(gpu, orc):
     assert [[t, cks(m)] for t, m in wg.log] == g["log"]
 
 
-@pytest.mark.parametrize("r,l,c,layout", [(5, 4, 3, 0), (5, 4, 3, 1), (200, 200, 200, 0), (130, 257, 66, 1)])
+@pytest.mark.parametrize("r,l,c,layout", [(5, 4, 3, 0), (5, 4, 3, 1), (200, 200, 200, 0), (130, 257, 66, 1),
+                                           (520, 140, 515, 0), (512, 512, 512, 1)])
 def test_aby3_matmul_protocol_parity(gpu, orc, r, l, c, layout):
     rng = np.random.default_rng(r + l + c)
     X, Y = rnd(rng, r * l), rnd(rng, l * c)
