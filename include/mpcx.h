@@ -103,6 +103,9 @@ int mpcx_aby3_matmul_local_rows(mpcx_ctx *ctx, const int64_t *X0blk, const int64
 int mpcx_aby3_vecmul_local(mpcx_ctx *ctx, const int64_t *X0, const int64_t *X1, const int64_t *Y0, const int64_t *Y1,
                            uint64_t n, uint64_t seed_next, uint64_t pop_next, uint64_t seed_prev, uint64_t pop_prev,
                            int64_t *Z0);
+/* vecbool_mul before the round (:253-256): Z0 = (X0&Y0)^(X1&Y0)^(X0&Y1), one byte per boolean */
+int mpcx_aby3_vecbool_mul_local(mpcx_ctx *ctx, const int8_t *X0, const int8_t *X1, const int8_t *Y0, const int8_t *Y1,
+                                uint64_t n, int8_t *Z0);
 /* reveal / reveal_matrix after the round (:142, :157): out = a + b + c ; reveal_bools (:171-174) and
  * reveal_bits (:287-288): out = a ^ b ^ c */
 int mpcx_aby3_reveal3(mpcx_ctx *ctx, const int64_t *a, const int64_t *b, const int64_t *c, int64_t *out, uint64_t n);

@@ -251,6 +251,12 @@ int mpcx_aby3_vecmul_local(mpcx_ctx *ctx, const int64_t *X0, const int64_t *X1, 
     });
 }
 
+int mpcx_aby3_vecbool_mul_local(mpcx_ctx *ctx, const int8_t *X0, const int8_t *X1, const int8_t *Y0, const int8_t *Y1,
+                                uint64_t n, int8_t *Z0) {
+    MPCX_REQUIRE((X0 && X1 && Y0 && Y1 && Z0) || n == 0, "mpcx_aby3_vecbool_mul_local: NULL pointer");
+    return ew_launch(ctx, n, [=] __device__(u64 i) { Z0[i] = (i8)((X0[i] & Y0[i]) ^ (X1[i] & Y0[i]) ^ (X0[i] & Y1[i])); });
+}
+
 int mpcx_aby3_reveal3(mpcx_ctx *ctx, const int64_t *a, const int64_t *b, const int64_t *c, int64_t *out, uint64_t n) {
     MPCX_REQUIRE((a && b && c && out) || n == 0, "mpcx_aby3_reveal3: NULL pointer");
     const u64 *x = (const u64 *)a, *y = (const u64 *)b, *z = (const u64 *)c;

@@ -1,0 +1,337 @@
+#include "ABY3Engine.hpp"
+
+#include "gpu_support.hpp"
+
+using mpcgpu::Dev;
+using mpcgpu::upload_string;
+
+namespace {
+struct Peers {
+    size_t next, prev;
+    explicit Peers(size_t id) : next((id + 1) % 3), prev((id + 2) % 3) {}
+};
+} // namespace
+
+ABY3Engine::ABY3Engine(VirtuleMessenger *_messenger, size_t _party_id) : messenger(_messenger), party_id(_party_id) {
+    message_send.resize(3);
+    message_recv.resize(3);
+    // prgs[k] is the stream shared with party k; prgs[party_id] is the private one
+    static const uint64_t pair_key[3][3] = {{KEY0, KEY01, KEY20}, {KEY01, KEY1, KEY12}, {KEY20, KEY12, KEY2}};
+    assert(party_id < 3);
+    for (size_t k = 0; k < 3; k++) prgs.push_back(PRgenerator(pair_key[party_id][k], 0));
+    gpu = mpcgpu::open_context();
+}
+
+ABY3Engine::~ABY3Engine() { mpcx_shutdown(gpu); }
+
+// ---- sharing: R = pop(next) - pop(prev) (+ X on party 0); send share 0 to prev, share 1 comes from next
+void ABY3Engine::share(const VecI64 &X_plain, array<VecI64, 2> &Xj) {
+    const size_t n = X_plain.size();
+    const Peers pe(party_id);
+    Dev<int64_t> out(gpu, n);
+    {
+        Dev<int64_t> x(gpu, X_plain.data(), n);
+        GPU_OK(gpu, mpcx_aby3_share_local(gpu, party_id == 0 ? x.p : nullptr, n, prgs[pe.next].init_seed,
+                                          prgs[pe.next].pops, prgs[pe.prev].init_seed, prgs[pe.prev].pops, out));
+    }
+    prgs[pe.next].advance(gpu, n);
+    prgs[pe.prev].advance(gpu, n);
+    message_send[pe.next].clear();
+    out.to_string(message_send[pe.prev]);
+    messenger->send_and_recv(message_send, message_recv);
+    string2vecI64(message_send[pe.prev], Xj[0]);
+    string2vecI64(message_recv[pe.next], Xj[1]);
+}
+
+void ABY3Engine::share_matrix(const MatrixXl &X_plain, array<MatrixXl, 2> &Xj) {
+    const size_t rows = X_plain.rows(), cols = X_plain.cols(), n = rows * cols;
+    const Peers pe(party_id);
+    Dev<int64_t> out(gpu, n);
+    {
+        Dev<int64_t> xc(gpu, X_plain.data(), n), xr(gpu, n);
+        if (party_id == 0 && n) GPU_OK(gpu, mpcx_relayout(gpu, xc, xr, rows, cols, 1, 0)); // the mask order is row-major
+        GPU_OK(gpu, mpcx_aby3_share_local(gpu, party_id == 0 ? xr.p : nullptr, n, prgs[pe.next].init_seed,
+                                          prgs[pe.next].pops, prgs[pe.prev].init_seed, prgs[pe.prev].pops, out));
+    }
+    prgs[pe.next].advance(gpu, n);
+    prgs[pe.prev].advance(gpu, n);
+    message_send[pe.next].clear();
+    out.to_string(message_send[pe.prev]);
+    messenger->send_and_recv(message_send, message_recv);
+    Xj[0].resize(rows, cols);
+    Xj[1].resize(rows, cols);
+    string2matrix(message_send[pe.prev], Xj[0]);
+    string2matrix(message_recv[pe.next], Xj[1]);
+}
+
+void ABY3Engine::share_bools(const vecbool &X_plain, array<vecbool, 2> &Xj) {
+    const size_t n = X_plain.size();
+    const Peers pe(party_id);
+    Dev<int8_t> out(gpu, n);
+    {
+        Dev<int8_t> x(gpu, X_plain.data(), n);
+        GPU_OK(gpu, mpcx_aby3_share_bools_local(gpu, party_id == 0 ? x.p : nullptr, n, prgs[pe.next].init_seed,
+                                                prgs[pe.next].pops, prgs[pe.prev].init_seed, prgs[pe.prev].pops, out));
+    }
+    prgs[pe.next].advance(gpu, n);
+    prgs[pe.prev].advance(gpu, n);
+    message_send[pe.next].clear();
+    out.to_string(message_send[pe.prev]);
+    messenger->send_and_recv(message_send, message_recv);
+    string2vecbool(message_send[pe.prev], Xj[0]);
+    string2vecbool(message_recv[pe.next], Xj[1]);
+}
+
+// ---- opening: send share 0 to next, receive the missing share from prev, combine the three
+void ABY3Engine::reveal(const array<VecI64, 2> &Xj, VecI64 &X_plain) {
+    const size_t n = Xj[0].size();
+    const Peers pe(party_id);
+    message_send[pe.prev].clear();
+    vecI642string(Xj[0], message_send[pe.next]);
+    messenger->send_and_recv(message_send, message_recv);
+    assert(message_recv[pe.prev].size() == n * sizeof(int64_t));
+    Dev<int64_t> a(gpu, n), b(gpu, Xj[0].data(), n), c(gpu, Xj[1].data(), n), out(gpu, n);
+    upload_string(a, message_recv[pe.prev]);
+    GPU_OK(gpu, mpcx_aby3_reveal3(gpu, a, b, c, out, n));
+    X_plain.resize(n);
+    out.down(X_plain.data(), n);
+}
+
+void ABY3Engine::reveal_matrix(const array<MatrixXl, 2> &Xj, MatrixXl &X_plain) {
+    const size_t rows = Xj[0].rows(), cols = Xj[0].cols(), n = rows * cols;
+    assert(Xj[1].rows() == rows && Xj[1].cols() == cols);
+    const Peers pe(party_id);
+    message_send[pe.prev].clear();
+    matrix2string(Xj[0], message_send[pe.next]);
+    messenger->send_and_recv(message_send, message_recv);
+    assert(message_recv[pe.prev].size() == n * sizeof(int64_t));
+    string other;
+    matrix2string(Xj[1], other);
+    Dev<int64_t> a(gpu, n), b(gpu, n), c(gpu, n), out(gpu, n);
+    upload_string(a, message_recv[pe.prev]);
+    upload_string(b, message_send[pe.next]);
+    upload_string(c, other);
+    GPU_OK(gpu, mpcx_aby3_reveal3(gpu, a, b, c, out, n));
+    out.to_string(other);
+    X_plain.resize(rows, cols);
+    string2matrix(other, X_plain);
+}
+
+void ABY3Engine::reveal_bools(const array<vecbool, 2> &Xj, vecbool &X_plain) {
+    const size_t n = Xj[0].size();
+    const Peers pe(party_id);
+    message_send[pe.prev].clear();
+    vecbool2string(Xj[0], message_send[pe.next]);
+    messenger->send_and_recv(message_send, message_recv);
+    assert(message_recv[pe.prev].size() == n);
+    Dev<int8_t> a(gpu, n), b(gpu, Xj[0].data(), n), c(gpu, Xj[1].data(), n), out(gpu, n);
+    upload_string(a, message_recv[pe.prev]);
+    GPU_OK(gpu, mpcx_aby3_reveal3_bools(gpu, a, b, c, out, n));
+    X_plain.resize(n);
+    out.down(X_plain.data(), n);
+}
+
+void ABY3Engine::reveal_bits(const array<VecI64, 2> &Xj, VecI64 &X_plain) {
+    const size_t n = Xj[0].size();
+    const Peers pe(party_id);
+    message_send[pe.prev].clear();
+    vecI642string(Xj[0], message_send[pe.next]);
+    messenger->send_and_recv(message_send, message_recv);
+    assert(message_recv[pe.prev].size() == n * sizeof(int64_t));
+    Dev<int64_t> a(gpu, n), b(gpu, Xj[0].data(), n), c(gpu, Xj[1].data(), n), out(gpu, n);
+    upload_string(a, message_recv[pe.prev]);
+    GPU_OK(gpu, mpcx_aby3_reveal3_bits(gpu, a, b, c, out, n));
+    X_plain.resize(n);
+    out.down(X_plain.data(), n);
+}
+
+// ---- products
+void ABY3Engine::matrix_mul(const array<MatrixXl, 2> &Xj, const array<MatrixXl, 2> &Yj, array<MatrixXl, 2> &Zj) {
+    const Peers pe(party_id);
+    const size_t rows = Xj[0].rows(), lens = Xj[0].cols(), cols = Yj[0].cols();
+    assert(Yj[0].rows() == lens);
+    assert(Xj[1].rows() == rows && Xj[1].cols() == lens);
+    assert(Yj[1].rows() == lens && Yj[1].cols() == cols);
+    Dev<int64_t> z(gpu, rows * cols);
+    {
+        Dev<int64_t> x0(gpu, Xj[0].data(), rows * lens), x1(gpu, Xj[1].data(), rows * lens);
+        Dev<int64_t> y0(gpu, Yj[0].data(), lens * cols), y1(gpu, Yj[1].data(), lens * cols);
+        // Eigen stores column-major (layout 1); the result comes back row-major = the wire order
+        GPU_OK(gpu, mpcx_aby3_matmul_local(gpu, x0, x1, y0, y1, rows, lens, cols, 1, prgs[pe.next].init_seed,
+                                           prgs[pe.next].pops, prgs[pe.prev].init_seed, prgs[pe.prev].pops, z));
+    }
+    prgs[pe.next].advance(gpu, rows * cols);
+    prgs[pe.prev].advance(gpu, rows * cols);
+    message_send[pe.next].clear();
+    z.to_string(message_send[pe.prev]);
+    messenger->send_and_recv(message_send, message_recv);
+    Zj[0].resize(rows, cols);
+    Zj[1].resize(rows, cols);
+    string2matrix(message_send[pe.prev], Zj[0]);
+    string2matrix(message_recv[pe.next], Zj[1]);
+}
+
+void ABY3Engine::vector_mul(const array<VecI64, 2> &Xj, const array<VecI64, 2> &Yj, array<VecI64, 2> &Zj) {
+    const Peers pe(party_id);
+    const size_t n = Xj[0].size();
+    assert((size_t)Xj[1].size() == n && (size_t)Yj[0].size() == n && (size_t)Yj[1].size() == n);
+    Dev<int64_t> z(gpu, n);
+    {
+        Dev<int64_t> x0(gpu, Xj[0].data(), n), x1(gpu, Xj[1].data(), n), y0(gpu, Yj[0].data(), n), y1(gpu, Yj[1].data(), n);
+        GPU_OK(gpu, mpcx_aby3_vecmul_local(gpu, x0, x1, y0, y1, n, prgs[pe.next].init_seed, prgs[pe.next].pops,
+                                           prgs[pe.prev].init_seed, prgs[pe.prev].pops, z));
+    }
+    prgs[pe.next].advance(gpu, n);
+    prgs[pe.prev].advance(gpu, n);
+    message_send[pe.next].clear();
+    z.to_string(message_send[pe.prev]);
+    messenger->send_and_recv(message_send, message_recv);
+    string2vecI64(message_send[pe.prev], Zj[0]);
+    string2vecI64(message_recv[pe.next], Zj[1]);
+}
+
+void ABY3Engine::vecbool_mul(const array<vecbool, 2> &Xj, const array<vecbool, 2> &Yj, array<vecbool, 2> &Zj) {
+    const Peers pe(party_id);
+    const size_t n = Xj[0].size();
+    assert(Xj[1].size() == n && Yj[0].size() == n && Yj[1].size() == n);
+    Dev<int8_t> z(gpu, n);
+    {
+        Dev<int8_t> x0(gpu, Xj[0].data(), n), x1(gpu, Xj[1].data(), n), y0(gpu, Yj[0].data(), n), y1(gpu, Yj[1].data(), n);
+        GPU_OK(gpu, mpcx_aby3_vecbool_mul_local(gpu, x0, x1, y0, y1, n, z));
+    }
+    message_send[pe.next].clear();
+    z.to_string(message_send[pe.prev]);
+    messenger->send_and_recv(message_send, message_recv);
+    string2vecbool(message_send[pe.prev], Zj[0]);
+    string2vecbool(message_recv[pe.next], Zj[1]);
+}
+
+// ---- carry-save step before msb: two rounds
+void ABY3Engine::add_prepare(const array<VecI64, 2> &Xj, array<VecI64, 2> &Gj, array<VecI64, 2> &Pj) {
+    const Peers pe(party_id);
+    const size_t n = Xj[0].size();
+    assert((size_t)Xj[1].size() == n);
+    Dev<int64_t> x0(gpu, Xj[0].data(), n), x1(gpu, Xj[1].data(), n), c0(gpu, n), c1(gpu, n);
+    GPU_OK(gpu, mpcx_aby3_add_prepare_step1(gpu, x0, x1, n, c0));
+    message_send[pe.next].clear();
+    c0.to_string(message_send[pe.prev]);
+    messenger->send_and_recv(message_send, message_recv);
+    assert(message_recv[pe.next].size() == n * sizeof(int64_t));
+    upload_string(c1, message_recv[pe.next]);
+    Dev<int64_t> p0(gpu, n), p1(gpu, n), g0(gpu, n);
+    GPU_OK(gpu, mpcx_aby3_add_prepare_step2(gpu, x0, x1, c0, c1, n, p0, p1, g0));
+    message_send[pe.next].clear();
+    g0.to_string(message_send[pe.prev]);
+    messenger->send_and_recv(message_send, message_recv);
+    string2vecI64(message_send[pe.prev], Gj[0]);
+    string2vecI64(message_recv[pe.next], Gj[1]);
+    Pj[0].resize(n);
+    Pj[1].resize(n);
+    p0.down(Pj[0].data(), n);
+    p1.down(Pj[1].data(), n);
+}
+
+// ---- most significant bit of the sum: 6 rounds of the carry tree
+void ABY3Engine::msb(const array<VecI64, 2> &Gj, const array<VecI64, 2> &Pj, array<vecbool, 2> &Zj) {
+    const Peers pe(party_id);
+    const size_t n = Gj[0].size();
+    assert(n == (size_t)Gj[1].size() && n == (size_t)Pj[0].size() && n == (size_t)Pj[1].size());
+    Dev<int64_t> p0(gpu, Pj[0].data(), n), p1(gpu, Pj[1].data(), n);
+    Dev<uint64_t> state(gpu, 4 * n);
+    {
+        Dev<int64_t> g0(gpu, Gj[0].data(), n), g1(gpu, Gj[1].data(), n);
+        GPU_OK(gpu, mpcx_aby3_msb_begin(gpu, g0, g1, p0, p1, n, state));
+    }
+    Dev<int8_t> msg(gpu, 64 * n);
+    for (size_t temp = 32; temp != 0; temp /= 2) {
+        const size_t bytes = 2 * temp * n;
+        GPU_OK(gpu, mpcx_aby3_msb_round_pre(gpu, state, n, temp, msg));
+        message_send[pe.next].clear();
+        message_send[pe.prev].resize(bytes);
+        if (bytes) msg.down(&message_send[pe.prev][0], bytes);
+        messenger->send_and_recv(message_send, message_recv);
+        assert(message_recv[pe.next].size() == bytes);
+        upload_string(msg, message_recv[pe.next]);
+        GPU_OK(gpu, mpcx_aby3_msb_round_post(gpu, state, n, temp, msg));
+    }
+    Dev<int8_t> z0(gpu, n), z1(gpu, n);
+    GPU_OK(gpu, mpcx_aby3_msb_final(gpu, state, p0, p1, n, z0, z1));
+    Zj[0].resize(n);
+    Zj[1].resize(n);
+    z0.down(Zj[0].data(), n);
+    z1.down(Zj[1].data(), n);
+}
+
+void ABY3Engine::trunc(const array<VecI64, 2> &Xj, array<VecI64, 2> &Yj, size_t number) {
+    assert(number < 64);
+    const Peers pe(party_id);
+    const size_t n = Xj[0].size();
+    assert(n == (size_t)Xj[1].size());
+    // parties 1 and 2 draw from the stream they share: prgs[2] on party 1, prgs[1] on party 2
+    const size_t k = party_id == 1 ? 2 : 1;
+    Dev<int64_t> x0(gpu, Xj[0].data(), n), x1(gpu, Xj[1].data(), n), y(gpu, n);
+    GPU_OK(gpu, mpcx_aby3_trunc_local(gpu, (int)party_id, x0, x1, n, (int)number, prgs[k].init_seed, prgs[k].pops, y));
+    if (party_id != 0) prgs[k].advance(gpu, n);
+    message_send[pe.next].clear();
+    y.to_string(message_send[pe.prev]);
+    messenger->send_and_recv(message_send, message_recv);
+    string2vecI64(message_send[pe.prev], Yj[0]);
+    string2vecI64(message_recv[pe.next], Yj[1]);
+}
+
+// ---- C = A * b for an arithmetic sharing A and a boolean sharing b: two three-party OTs in one round
+void ABY3Engine::bit_inject(const array<VecI64, 2> &Aj, const array<vecbool, 2> &Bj, array<VecI64, 2> &Cj) {
+    const size_t n = Aj[0].size();
+    assert(n == (size_t)Aj[1].size() && n == Bj[0].size() && n == Bj[1].size());
+    const size_t w = n * sizeof(int64_t);
+    for (auto &m : message_send) m.clear();
+    Dev<int64_t> a0(gpu, Aj[0].data(), n), a1(gpu, Aj[1].data(), n), c0(gpu, n), c1(gpu, n);
+    Dev<int8_t> b0(gpu, Bj[0].data(), n), b1(gpu, Bj[1].data(), n);
+    if (party_id == 0) {
+        PRgenerator &s01 = prgs[1], &s20 = prgs[2];
+        const uint64_t pop01 = s01.pops, pop20 = s20.pops;
+        Dev<int64_t> to1(gpu, 2 * n), to2(gpu, 3 * n), from1(gpu, 2 * n), from2(gpu, n);
+        GPU_OK(gpu, mpcx_aby3_bit_inject_p0_pre(gpu, a0, b0, b1, n, s01.init_seed, pop01, s20.init_seed, pop20, to1, to2));
+        s01.advance(gpu, 6 * n);
+        s20.advance(gpu, 3 * n);
+        to1.to_string(message_send[1]);
+        to2.to_string(message_send[2]);
+        messenger->send_and_recv(message_send, message_recv);
+        assert(message_recv[1].size() == 2 * w && message_recv[2].size() == w);
+        upload_string(from1, message_recv[1]);
+        upload_string(from2, message_recv[2]);
+        GPU_OK(gpu, mpcx_aby3_bit_inject_p0_post(gpu, b0, n, s01.init_seed, pop01, s20.init_seed, pop20, from1, from2, c0, c1));
+    } else if (party_id == 1) {
+        PRgenerator &s01 = prgs[0], &s12 = prgs[2];
+        const uint64_t pop01 = s01.pops, pop12 = s12.pops;
+        Dev<int64_t> to0(gpu, 2 * n), to2(gpu, 3 * n), from0(gpu, 2 * n), from2(gpu, n);
+        GPU_OK(gpu, mpcx_aby3_bit_inject_p1_pre(gpu, a0, a1, b0, b1, n, s01.init_seed, pop01, s12.init_seed, pop12, to0, to2));
+        s01.advance(gpu, 6 * n);
+        s12.advance(gpu, 3 * n);
+        to0.to_string(message_send[0]);
+        to2.to_string(message_send[2]);
+        messenger->send_and_recv(message_send, message_recv);
+        assert(message_recv[0].size() == 2 * w && message_recv[2].size() == w);
+        upload_string(from0, message_recv[0]);
+        upload_string(from2, message_recv[2]);
+        GPU_OK(gpu, mpcx_aby3_bit_inject_p1_post(gpu, b1, n, s01.init_seed, pop01, s12.init_seed, pop12, from0, from2, c0, c1));
+    } else {
+        PRgenerator &s20 = prgs[0], &s12 = prgs[1];
+        const uint64_t pop20 = s20.pops, pop12 = s12.pops;
+        Dev<int64_t> to0(gpu, n), to1(gpu, n), from0(gpu, 3 * n), from1(gpu, 3 * n);
+        GPU_OK(gpu, mpcx_aby3_bit_inject_p2_pre(gpu, b0, b1, n, s20.init_seed, pop20, s12.init_seed, pop12, to0, to1));
+        s20.advance(gpu, 3 * n);
+        s12.advance(gpu, 3 * n);
+        to0.to_string(message_send[0]);
+        to1.to_string(message_send[1]);
+        messenger->send_and_recv(message_send, message_recv);
+        assert(message_recv[0].size() == 3 * w && message_recv[1].size() == 3 * w);
+        upload_string(from0, message_recv[0]);
+        upload_string(from1, message_recv[1]);
+        GPU_OK(gpu, mpcx_aby3_bit_inject_p2_post(gpu, b0, b1, n, s20.init_seed, pop20, s12.init_seed, pop12, from0, from1, c0, c1));
+    }
+    Cj[0].resize(n);
+    Cj[1].resize(n);
+    c0.down(Cj[0].data(), n);
+    c1.down(Cj[1].data(), n);
+}

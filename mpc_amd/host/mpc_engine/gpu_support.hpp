@@ -1,0 +1,66 @@
+// Small helpers the host engines use to drive the GPU library (include/mpcx.h): one context per engine,
+// RAII device buffers, and the reference's error convention (no exceptions, no return codes: a failed
+// call prints the library's message and aborts, like a failed assert).
+#pragma once
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string>
+#include <vector>
+
+#include "../../../include/mpcx.h"
+
+#define GPU_OK(ctx, call)                                                              \
+    do {                                                                               \
+        if ((call) != 0) {                                                             \
+            fprintf(stderr, "%s:%d: %s\n", __FILE__, __LINE__, mpcx_last_error(ctx)); \
+            abort();                                                                   \
+        }                                                                              \
+    } while (0)
+
+namespace mpcgpu {
+
+inline mpcx_ctx *open_context() {
+    mpcx_ctx *ctx = nullptr;
+    const char *dev = getenv("MPCX_DEVICE");
+    if (mpcx_init(dev ? atoi(dev) : 0, &ctx) != 0) {
+        fprintf(stderr, "mpcx_init: %s\n", mpcx_last_error(nullptr));
+        abort();
+    }
+    return ctx;
+}
+
+// typed device buffer owned by this object
+template <class T> class Dev {
+  public:
+    mpcx_ctx *ctx;
+    T *p = nullptr;
+    size_t n = 0;
+    Dev(mpcx_ctx *c, size_t count) : ctx(c), n(count) {
+        void *q = nullptr;
+        GPU_OK(ctx, mpcx_malloc(ctx, (count ? count : 1) * sizeof(T), &q));
+        p = (T *)q;
+    }
+    Dev(mpcx_ctx *c, const T *host, size_t count) : Dev(c, count) { up(host, count); }
+    Dev(const Dev &) = delete;
+    Dev &operator=(const Dev &) = delete;
+    ~Dev() { mpcx_free(ctx, p); }
+    void up(const void *host, size_t count) { GPU_OK(ctx, mpcx_h2d(ctx, p, host, count * sizeof(T))); }
+    void down(void *host, size_t count, size_t first = 0) const {
+        GPU_OK(ctx, mpcx_d2h(ctx, host, p + first, count * sizeof(T)));
+    }
+    // the whole buffer as a wire payload
+    void to_string(std::string &s) const {
+        s.resize(n * sizeof(T));
+        if (n) down(&s[0], n);
+    }
+    operator T *() { return p; }
+    operator const T *() const { return p; }
+};
+
+template <class T> inline void upload_string(Dev<T> &d, const std::string &s, size_t byte_off = 0, size_t bytes = (size_t)-1) {
+    if (bytes == (size_t)-1) bytes = s.size() - byte_off;
+    if (bytes) GPU_OK(d.ctx, mpcx_h2d(d.ctx, d.p, s.data() + byte_off, bytes));
+}
+
+} // namespace mpcgpu

@@ -1,0 +1,282 @@
+// Self-test of the host engines: the three parties run as three threads of this process over the
+// in-process messenger, every engine method is exercised the way the reference's own tests exercise it
+// (test/test_ABY3.cpp, test/test_securenn.cpp: reveal(op(share(x))) == op(x)), and share checksums are
+// printed as "KAT <name> <party> <hex>" lines so that a harness can compare them with known answers.
+// Exit code 0 = every check passed.
+#include <stdio.h>
+#include <stdlib.h>
+#include <atomic>
+#include <thread>
+
+#include "../mpc_engine/ABY3Engine.hpp"
+#include "../mpc_engine/SecurennEngine.hpp"
+#include "../utils/InProcMessenger.hpp"
+#include "../utils/util.hpp"
+
+static std::atomic<int> failures{0};
+#define CHECK(cond)                                                                  \
+    do {                                                                             \
+        if (!(cond)) {                                                               \
+            fprintf(stderr, "CHECK failed: %s (%s:%d)\n", #cond, __FILE__, __LINE__); \
+            failures++;                                                              \
+        }                                                                            \
+    } while (0)
+
+static uint64_t fnv(const int64_t *w, size_t n) {
+    uint64_t h = 0xCBF29CE484222325ull;
+    for (size_t i = 0; i < n; i++) {
+        h ^= (uint64_t)w[i];
+        h *= 0x100000001B3ull;
+    }
+    return h;
+}
+static uint64_t fnv_rowmajor(const MatrixXl &m) {
+    vector<int64_t> v;
+    matrix2vector(m, v);
+    return fnv(v.data(), v.size());
+}
+
+static void aby3_party(InProcHub *hub, size_t p) {
+    InProcMessenger msgr(hub, p);
+    ABY3Engine e(&msgr, p);
+    // share -> reveal identities (vector, matrix, booleans)
+    {
+        PRgenerator g(20, 0);
+        const size_t n = 10;
+        VecI64 X(n), Xr;
+        for (size_t i = 0; i < n; i++) X[i] = g.pop_int64();
+        array<VecI64, 2> Xj;
+        e.share(X, Xj);
+        e.reveal(Xj, Xr);
+        CHECK(Xr == X);
+        MatrixXl M(5, 4), Mr;
+        for (size_t i = 0; i < 5; i++)
+            for (size_t j = 0; j < 4; j++) M(i, j) = g.pop_int64();
+        array<MatrixXl, 2> Mj;
+        e.share_matrix(M, Mj);
+        e.reveal_matrix(Mj, Mr);
+        CHECK(Mr == M);
+        vecbool B(n), Br;
+        for (size_t i = 0; i < n; i++) B[i] = g.pop_bool();
+        array<vecbool, 2> Bj;
+        e.share_bools(B, Bj);
+        e.reveal_bools(Bj, Br);
+        CHECK(Br == B);
+    }
+    // products
+    {
+        PRgenerator g(31, 0);
+        MatrixXl X(5, 4), Y(4, 3), Z;
+        for (size_t i = 0; i < 5; i++)
+            for (size_t j = 0; j < 4; j++) X(i, j) = g.pop_int64();
+        for (size_t i = 0; i < 4; i++)
+            for (size_t j = 0; j < 3; j++) Y(i, j) = g.pop_int64();
+        array<MatrixXl, 2> Xj, Yj, Zj;
+        e.share_matrix(X, Xj);
+        e.share_matrix(Y, Yj);
+        e.matrix_mul(Xj, Yj, Zj);
+        e.reveal_matrix(Zj, Z);
+        CHECK(Z == X * Y);
+        const size_t n = 10;
+        VecI64 U(n), V(n), Wv;
+        for (size_t i = 0; i < n; i++) {
+            U[i] = g.pop_int64();
+            V[i] = g.pop_int64();
+        }
+        array<VecI64, 2> Uj, Vj, Wj;
+        e.share(U, Uj);
+        e.share(V, Vj);
+        e.vector_mul(Uj, Vj, Wj);
+        e.reveal(Wj, Wv);
+        CHECK(Wv == U * V);
+        vecbool A(100), B(100), C;
+        for (size_t i = 0; i < 100; i++) {
+            A[i] = g.pop_bool();
+            B[i] = g.pop_bool();
+        }
+        array<vecbool, 2> Aj, Bj, Cj;
+        e.share_bools(A, Aj);
+        e.share_bools(B, Bj);
+        e.vecbool_mul(Aj, Bj, Cj);
+        e.reveal_bools(Cj, C);
+        for (size_t i = 0; i < 100; i++) CHECK(C[i] == A[i] * B[i]);
+    }
+    // msb / bit_inject / trunc
+    {
+        PRgenerator g(21, 0);
+        const size_t n = 1000;
+        VecI64 X(n), Wr;
+        for (size_t i = 0; i < n; i++) X[i] = g.pop_int64();
+        X[0] = 0, X[1] = -1, X[2] = 1, X[3] = INT64_MIN, X[4] = INT64_MAX, X[5] = -2;
+        array<VecI64, 2> Xj, Gj, Pj, Wj;
+        array<vecbool, 2> Zj;
+        vecbool Z;
+        e.share(X, Xj);
+        e.add_prepare(Xj, Gj, Pj);
+        e.msb(Gj, Pj, Zj);
+        e.reveal_bools(Zj, Z);
+        for (size_t i = 0; i < n; i++) CHECK(Z[i] == (X[i] < 0));
+        e.bit_inject(Xj, Zj, Wj);
+        e.reveal(Wj, Wr);
+        for (size_t i = 0; i < n; i++) CHECK(Wr[i] == X[i] * Z[i]);
+        printf("KAT aby3_relu_1000_C0 %zu %016lX\n", p, (unsigned long)fnv(Wj[0].data(), n));
+        VecI64 T(10), Tr;
+        for (size_t i = 0; i < 10; i++) T[i] = g.pop_int64() >> 32;
+        array<VecI64, 2> Tj, Sj;
+        e.share(T, Tj);
+        e.trunc(Tj, Sj, 16);
+        e.reveal(Sj, Tr);
+        for (size_t i = 0; i < 10; i++) CHECK(Tr[i] == (T[i] >> 16) || Tr[i] == (T[i] >> 16) - 1);
+    }
+}
+
+// known-answer run on FRESH engines: X then Y 64x64 row-major from PRgenerator(20,0)
+static void aby3_kat_party(InProcHub *hub, size_t p) {
+    InProcMessenger msgr(hub, p);
+    ABY3Engine e(&msgr, p);
+    PRgenerator g(20, 0);
+    const size_t n = 64;
+    MatrixXl X(n, n), Y(n, n), Z;
+    for (size_t i = 0; i < n; i++)
+        for (size_t j = 0; j < n; j++) X(i, j) = g.pop_int64();
+    for (size_t i = 0; i < n; i++)
+        for (size_t j = 0; j < n; j++) Y(i, j) = g.pop_int64();
+    array<MatrixXl, 2> Xj, Yj, Zj;
+    e.share_matrix(X, Xj);
+    e.share_matrix(Y, Yj);
+    e.matrix_mul(Xj, Yj, Zj);
+    e.reveal_matrix(Zj, Z);
+    CHECK(Z == X * Y);
+    printf("KAT aby3_matmul_64_Z0 %zu %016lX\n", p, (unsigned long)fnv_rowmajor(Zj[0]));
+    printf("KAT aby3_matmul_64_Zplain %zu %016lX\n", p, (unsigned long)fnv_rowmajor(Z));
+}
+
+static void snn_party(InProcHub *hub, size_t p) {
+    InProcMessenger msgr(hub, p);
+    SecurennEngine e(&msgr, p);
+    {
+        // msb at n = 1000 on fresh engines: a = pop/2 from PRgenerator(22,0) after 67000 pops
+        PRgenerator g(22, 0);
+        const size_t n = 1000;
+        for (size_t i = 0; i < 67 * n; i++) g.pop_int64();
+        vector<int64_t> A(n), Aj, Bj, B;
+        for (auto &a : A) a = g.pop_int64() / 2;
+        e.share(A, Aj);
+        e.msb(Aj, Bj);
+        e.reveal(Bj, B);
+        for (size_t i = 0; i < n; i++) CHECK(B[i] == (A[i] < 0));
+        if (p != 2) printf("KAT snn_msb_1000_B %zu %016lX\n", p, (unsigned long)fnv(Bj.data(), n));
+    }
+    {
+        vector<int64_t> X(10), Xj, Xr;
+        for (size_t i = 0; i < 10; i++) X[i] = (int64_t)(i * 0x123456789ull) - 77;
+        e.share(X, Xj);
+        e.reveal(Xj, Xr);
+        CHECK(Xr == X);
+    }
+    {
+        PRgenerator g(33 + p, 0); // each party brings its own additive shares
+        const size_t n = 5;
+        vector<int64_t> Xj(n), Yj(n), Zj, X, Y, Z;
+        for (size_t i = 0; i < n; i++) {
+            Xj[i] = g.pop_int64();
+            Yj[i] = g.pop_int64();
+        }
+        e.vector_mul(Xj, Yj, Zj);
+        e.reveal(Xj, X);
+        e.reveal(Yj, Y);
+        e.reveal(Zj, Z);
+        for (size_t i = 0; i < n; i++) CHECK((uint64_t)Z[i] == (uint64_t)X[i] * (uint64_t)Y[i]);
+        const size_t rows = 3, lens = 4, cols = 5;
+        MatrixXl Mx(rows, lens), My(lens, cols), Mz, Px, Py, Pz;
+        for (size_t i = 0; i < rows; i++)
+            for (size_t j = 0; j < lens; j++) Mx(i, j) = g.pop_int64();
+        for (size_t i = 0; i < lens; i++)
+            for (size_t j = 0; j < cols; j++) My(i, j) = g.pop_int64();
+        e.matrix_mul(Mx, My, Mz);
+        e.reveal_matrix(Mx, Px);
+        e.reveal_matrix(My, Py);
+        e.reveal_matrix(Mz, Pz);
+        CHECK(Pz == Px * Py);
+    }
+    {
+        // privateCompare with the r = -1 corner every fifth element
+        PRgenerator g(22, 0);
+        const size_t n = 50;
+        vector<int64_t> X(n), R(n);
+        vector<int8_t> B1(n), B2(n), Bp;
+        vector<zpshare> xs[2];
+        xs[0].resize(n);
+        xs[1].resize(n);
+        for (size_t i = 0; i < n; i++) {
+            X[i] = g.pop_int64();
+            R[i] = g.pop_int64();
+            if (i % 5 == 2) R[i] = -1;
+            B1[i] = g.pop_bool();
+            for (size_t k = 0; k < 64; k++) {
+                xs[0][i][k] = (uint16_t)g.pop_int64() % P;
+                xs[1][i][k] = (uint16_t)((((uint64_t)X[i] >> k) & 1) + P - xs[0][i][k]) % P;
+            }
+        }
+        vector<zpshare> back;
+        e.reveal_zp(xs[p == 2 ? 0 : p], back);
+        e.privateCompare(xs[p == 2 ? 0 : p], B1, R, B2);
+        e.reveal_vec_bools(p == 2 ? B2 : B1, Bp);
+        if (p != 2)
+            for (size_t i = 0; i < n; i++) {
+                CHECK(Bp[i] == ((uint64_t)X[i] > (uint64_t)R[i]));
+                for (size_t k = 0; k < 64; k++) CHECK(back[i][k] == (((uint64_t)X[i] >> k) & 1));
+            }
+    }
+    {
+        // shareConvert + msb_L_1 on the corner values of test/test_securenn.cpp:247-251
+        PRgenerator g(44, 0);
+        const size_t n = 10;
+        vector<int64_t> A(n), Aj, Yj, Y, Bj, B;
+        for (auto &a : A) {
+            a = g.pop_int64();
+            if (a == -1) a = 1;
+        }
+        A[0] = 0, A[1] = INT64_MIN, A[2] = -2, A[3] = 1, A[4] = INT64_MAX;
+        e.share(A, Aj);
+        e.shareConvert(Aj, Yj);
+        e.reveal_L_1(Yj, Y);
+        if (p != 2) CHECK(Y == A);
+        e.msb_L_1(Yj, Bj);
+        e.reveal(Bj, B);
+        for (size_t i = 0; i < n; i++) CHECK(B[i] == (Y[i] < 0));
+    }
+    {
+        // the reference benchmark's own size, which needs 256000 buffer words (> BUFF_NUM)
+        PRgenerator g(23, 0);
+        const size_t n = 2000;
+        vector<int64_t> A(n), Aj, Bj, B, Mj, M;
+        for (auto &a : A) a = g.pop_int64() / 2;
+        e.share(A, Aj);
+        e.msb(Aj, Bj);
+        e.vector_mul(Aj, Bj, Mj); // a * [a < 0], ReLU(a) = a - that
+        e.reveal(Bj, B);
+        e.reveal(Mj, M);
+        for (size_t i = 0; i < n; i++) CHECK(B[i] == (A[i] < 0) && M[i] == A[i] * B[i]);
+    }
+}
+
+template <class F> static void run3(F party) {
+    InProcHub hub;
+    std::thread t0(party, &hub, 0), t1(party, &hub, 1), t2(party, &hub, 2);
+    t0.join();
+    t1.join();
+    t2.join();
+}
+
+int main() {
+    run3(aby3_kat_party);
+    run3(aby3_party);
+    run3(snn_party);
+    if (failures.load()) {
+        printf("host_selftest: %d check(s) FAILED\n", failures.load());
+        return 1;
+    }
+    printf("host_selftest: all checks passed\n");
+    return 0;
+}
