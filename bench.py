@@ -28,6 +28,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
+from mpc_amd.sharding import aby3_matmul_pop_plan, matmul_row_block  # noqa: E402
+
 KEY01, KEY12, KEY20, KEYS = 0xAB01, 0xBC12, 0xCA20, 0xF0
 INT8_PEAK_TOPS = 5033.0  # 256 CU x 4 SIMD x 2048 int8 op/clk x 2.4 GHz (2x the 2.5 PF bf16 dense peak)
 HBM_PEAK_GBS = 8000.0
@@ -48,7 +50,9 @@ class Aby3MatmulJob:
         self.ctx, self.torch, self.n, self.rank, self.world = ctx, torch, n, rank, world
         self.rows, self.l, self.c = n, n, n
         self.rows_total = n * world
-        self.row0 = rank * n
+        self.row0, rows = matmul_row_block(self.rows_total, world, rank)
+        assert rows == n
+        self.plan = aby3_matmul_pop_plan(self.rows_total, self.l, self.c)
         i64 = torch.int64
         e = lambda k: torch.empty(k, dtype=i64, device=dev)
         # plaintext inputs: X then Y row-major from PRgenerator(20,0).pop_int64()
@@ -61,14 +65,15 @@ class Aby3MatmulJob:
         self.Zfull = [e(self.rows_total * self.c) for _ in range(3)] if world > 1 else None
         self.Zplain = [e(self.rows * self.c) for _ in range(3)]
         # pop-stream checkpoints for everything a step consumes (fresh engines every step)
-        pops = self.rows_total * self.l + self.l * self.c + self.rows_total * self.c
+        pops = self.plan["total"]
         for k in (KEY01, KEY12, KEY20):
             ctx.call("prg_ckpt_build", k, 0, pops, 0)
         ctx.call("prg_ckpt_build", 20, 0, self.rows_total * self.l + self.l * self.c, 0)
         ctx.sync()
 
     def step(self):
-        ctx, n2x, n2y = self.ctx, self.rows_total * self.l, self.l * self.c
+        ctx, n2y = self.ctx, self.l * self.c
+        n2x, pm = self.plan["share_y"], self.plan["matmul"]
         for j in range(3):
             nx, pv = (j + 1) % 3, (j + 2) % 3
             sn, sp = pair_seed(j, nx), pair_seed(j, pv)
@@ -79,7 +84,7 @@ class Aby3MatmulJob:
             nx, pv = (j + 1) % 3, (j + 2) % 3
             sn, sp = pair_seed(j, nx), pair_seed(j, pv)
             ctx.call("aby3_matmul_local_rows", self.RX[j], self.RX[nx], self.RY[j], self.RY[nx], self.rows, self.l,
-                     self.c, self.row0, sn, n2x + n2y, sp, n2x + n2y, self.Z0[j])
+                     self.c, self.row0, sn, pm, sp, pm, self.Z0[j])
         if self.world > 1:
             import torch.distributed as dist
             for j in range(3):  # the message party j hands to the messenger: all row-blocks of Z0
