@@ -68,15 +68,15 @@ int mpcx_init(int device, mpcx_ctx **out) {
 
 int mpcx_shutdown(mpcx_ctx *ctx) {
     if (!ctx) return 0;
-    hipSetDevice(ctx->device);
-    hipStreamSynchronize(ctx->stream);
-    if (ctx->ws) hipFree(ctx->ws);
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->ws) (void)hipFree(ctx->ws);
     for (auto &v : ctx->prof_ev)
         for (auto &p : v) {
             (void)hipEventDestroy(p.first);
             (void)hipEventDestroy(p.second);
         }
-    if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return 0;
 }

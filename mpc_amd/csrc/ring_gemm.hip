@@ -6,9 +6,14 @@
 // and every P_s fits an int32 accumulator as long as (s+1) * K * 2^14 < 2^31, i.e. K <= 16383 per
 // accumulation chunk (larger K is split into chunks that are recombined in 64 bits).
 //
-// Pipeline:  split_limbs (u64 matrix -> 8 int8 planes, K contiguous, optionally two sources
-// concatenated along K)  ->  limb_gemm (MFMA v_mfma_i32_32x32x32_i8, LDS-staged tiles, one int32
-// plane per s)  ->  combine (shift-add the planes in 64 bits, fuse the PRG mask / accumulation).
+// Pipeline:  split_limbs (u64 matrix -> 8 int8 limb planes, optionally two sources concatenated
+// along K)  ->  limb_gemm (v_mfma_i32_32x32x32_i8; one int32 plane per s)  ->  combine (shift-add the
+// planes in 64 bits, fuse the PRG mask / accumulation).
+//
+// Limb planes are stored K-blocked: plane[i][kb][row][32 bytes], kb = k / 32, so that the operand
+// tile of one K step (a run of rows x 32 bytes) is one contiguous, fully used piece of memory.
+#include <cstdlib>
+
 #include "mpcx_internal.h"
 
 namespace {
@@ -16,12 +21,13 @@ namespace {
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
-constexpr u32 BM = 128, BN = 128, BK = 128; // block tile (BK in int8 = bytes)
-constexpr u32 LDS_PITCH = BK + 16;          // 144 B: consecutive rows land on distinct 16-B bank slots
+constexpr u32 RM = 128, RN = 64, RK = 32; // block tile: 128 x 64 outputs, 32 bytes of K per step
+constexpr u32 KPAD = 64;                  // K extent of each concatenated part is padded to this
+constexpr u32 STAGE_BYTES = 8 * (RM + RN) * RK; // 48 KiB: all 8 limbs of the A and B tiles of one step
 
 // ---------------------------------------------------------------- split
-// planes[i][o][koff + k] = digit_i( src(o,k) (+ src2(o,k)) ),  src(o,k) = src[o*so + k*sk]
-// grid: (ceil(Kpart/64), Op/64); everything outside [0,O) x [0,K) is written as 0.
+// planes[i][kb][o][k%32] = digit_i( src(o,k) (+ src2(o,k)) ),  src(o,k) = src[o*so + k*sk], k offset by koff
+// grid: (Kpart/64, Op/64); everything outside [0,O) x [0,K) is written as 0.
 __global__ __launch_bounds__(256) void split_limbs_kernel(const u64 *__restrict__ src, const u64 *__restrict__ src2,
                                                           u64 O, u64 K, u64 so, u64 sk, i8 *__restrict__ planes,
                                                           u64 Op, u64 Kp, u64 koff) {
@@ -42,13 +48,15 @@ __global__ __launch_bounds__(256) void split_limbs_kernel(const u64 *__restrict_
         tile[oo][ko] = v;
     }
     __syncthreads();
-    const u32 oo = tid >> 2, kc = tid & 3;
+    // thread -> (row oo, 16 consecutive k): lanes 0..63 of a wave take 64 rows of the same 16-byte column
+    const u32 oo = tid & 63, kc = tid >> 6;
     u64 y[16];
 #pragma unroll
     for (u32 q = 0; q < 16; q++)
         y[q] = (tile[oo][kc * 16 + q] + 0x8080808080808080ull) ^ 0x8080808080808080ull;
     const u64 plane_stride = Op * Kp;
-    i8 *dst = planes + (o0 + oo) * Kp + koff + k0 + kc * 16;
+    const u64 kg = koff + k0 + kc * 16;
+    i8 *dst = planes + ((kg >> 5) * Op + o0 + oo) * RK + (kg & 31);
 #pragma unroll
     for (u32 i = 0; i < 8; i++) {
         u32 w[4];
@@ -62,216 +70,119 @@ __global__ __launch_bounds__(256) void split_limbs_kernel(const u64 *__restrict_
 }
 
 // ---------------------------------------------------------------- gemm
-// Cpl[s][m][n] = sum_{i<=s} sum_k Apl[i][m][k] * Bpl[s-i][n][k]   (int32), for the block's 128x128 tile.
-// 4 waves as 2x2, each 64x64 = 2x2 MFMA tiles of 32x32.  Operand fragments: lane l supplies row
-// (l & 31) and the 16 bytes k = 16*(l >> 5) .. +16 of a 32-deep K step for both A and B, so each k
-// is multiplied exactly once whatever the hardware's internal k order.  Accumulator map (all gfx950
-// 32x32 MFMAs): col = l & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(l >> 5).
-__global__ __launch_bounds__(256) void limb_gemm_kernel(const i8 *__restrict__ Apl, const i8 *__restrict__ Bpl,
-                                                        i32 *__restrict__ Cpl, u32 Mp, u32 Np, u32 Kp, u32 tiles_m,
+// Cpl[s][m][n] = sum_{i+j=s} sum_k Apl[i][m][k] * Bpl[j][n][k]  (int32) for one 128 x 64 block tile.
+//
+// Eight waves as 4(M) x 2(N); every wave owns ONE 32x32 output tile and keeps all eight s-accumulators
+// (8 x 16 registers).  Per K step the block stages the 8 limb tiles of A (8 x 128 x 32 B) and of B
+// (8 x 64 x 32 B) once -- 48 KiB -- and every wave issues the 36 MFMAs i+j <= 7 on them: each staged
+// byte feeds 192 multiply-adds (a plain one-accumulator 256x256 tiling feeds 128), and the accumulators
+// are written out once, after the whole K loop.
+//
+// Staging is LDS-DMA (global_load_lds, 16 B per lane, two 48 KiB buffers: step t+1 lands while step t
+// is multiplied).  A DMA wave-instruction writes 1 KiB linearly = 32 rows x 32 B, so the bank swizzle
+// is applied to the per-lane SOURCE address and undone on the ds_read: 16-byte half h of row r is kept
+// at half h ^ ((r >> 3) & 1), which spreads the 16 rows of a ds_read_b128 lane group over all 64 banks.
+//
+// Operand fragments: lane l supplies row (l & 31) and bytes 16*(l >> 5) .. +16 of the 32-byte step for
+// both A and B, so every k meets its partner exactly once whatever the hardware's internal k order.
+// Accumulator map (all gfx950 32x32 MFMAs): col = l & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(l >> 5).
+//
+// ABL (development ablation, 0 in production): 1 = no MFMA / fragment reads, 2 = no operand staging.
+template <int ABL>
+__global__ __launch_bounds__(512) void limb_gemm_kernel(const i8 *__restrict__ Apl, const i8 *__restrict__ Bpl,
+                                                        i32 *__restrict__ Cpl, u32 Mp, u32 Np, u32 nkb, u32 tiles_m,
                                                         u32 tiles_n) {
-    __shared__ __attribute__((aligned(16))) i8 lds[(BM + BN) * LDS_PITCH];
-    i8 *As = lds, *Bs = lds + BM * LDS_PITCH;
-    const u32 tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const u32 wm = wid >> 1, wn = wid & 1, lr = lane & 31, lh = lane >> 5;
-
-    // XCD-aware tile order: workgroups b, b+8, b+16.. share an XCD (and its L2); give each XCD a
-    // contiguous run of tiles so that neighbours reuse the same A row-panel / B column-panels.
-    const u32 nwg = tiles_m * tiles_n;
-    const u32 bid = blockIdx.x;
-    const u32 q = nwg / 8, rem = nwg % 8, xcd = bid % 8;
-    const u32 swz = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + bid / 8;
-    const u32 tm = swz / tiles_n, tn = swz % tiles_n;
-
-    const u64 strideA = (u64)Mp * Kp, strideB = (u64)Np * Kp, strideC = (u64)Mp * Np;
-    const i8 *Ablk = Apl + (u64)tm * BM * Kp;
-    const i8 *Bblk = Bpl + (u64)tn * BN * Kp;
-
-    for (u32 s = 0; s < 8; s++) {
-        v16i acc[2][2];
-#pragma unroll
-        for (int a = 0; a < 2; a++)
-#pragma unroll
-            for (int b = 0; b < 2; b++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) acc[a][b][r] = 0;
-        for (u32 i = 0; i <= s; i++) {
-            const i8 *Ap = Ablk + i * strideA;
-            const i8 *Bp = Bblk + (s - i) * strideB;
-            for (u32 k0 = 0; k0 < Kp; k0 += BK) {
-                uint4 ra[4], rb[4];
-#pragma unroll
-                for (u32 p = 0; p < 4; p++) {
-                    const u32 c = tid + 256 * p, row = c >> 3, seg = c & 7;
-                    ra[p] = *(const uint4 *)(Ap + (u64)row * Kp + k0 + seg * 16);
-                    rb[p] = *(const uint4 *)(Bp + (u64)row * Kp + k0 + seg * 16);
-                }
-                __syncthreads(); // previous tile fully consumed
-#pragma unroll
-                for (u32 p = 0; p < 4; p++) {
-                    const u32 c = tid + 256 * p, row = c >> 3, seg = c & 7;
-                    *(uint4 *)(As + row * LDS_PITCH + seg * 16) = ra[p];
-                    *(uint4 *)(Bs + row * LDS_PITCH + seg * 16) = rb[p];
-                }
-                __syncthreads();
-#pragma unroll
-                for (u32 kk = 0; kk < BK / 32; kk++) {
-                    v4i a[2], b[2];
-#pragma unroll
-                    for (u32 t = 0; t < 2; t++) {
-                        a[t] = *(const v4i *)(As + (wm * 64 + t * 32 + lr) * LDS_PITCH + kk * 32 + lh * 16);
-                        b[t] = *(const v4i *)(Bs + (wn * 64 + t * 32 + lr) * LDS_PITCH + kk * 32 + lh * 16);
-                    }
-#pragma unroll
-                    for (u32 mi = 0; mi < 2; mi++)
-#pragma unroll
-                        for (u32 ni = 0; ni < 2; ni++)
-                            acc[mi][ni] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
-                }
-            }
-        }
-        i32 *Cs = Cpl + s * strideC;
-#pragma unroll
-        for (u32 mi = 0; mi < 2; mi++)
-#pragma unroll
-            for (u32 ni = 0; ni < 2; ni++)
-#pragma unroll
-                for (u32 r = 0; r < 16; r++) {
-                    const u32 row = tm * BM + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    const u32 col = tn * BN + wn * 64 + ni * 32 + lr;
-                    Cs[(u64)row * Np + col] = acc[mi][ni][r];
-                }
-    }
-}
-
-// ---------------------------------------------------------------- gemm, large tiles
-// Same contraction on a 256x256 block tile: 8 waves as 2(M) x 4(N), each 128x64 = 4x2 MFMA tiles.
-// K is walked as ONE flat sequence of 128-byte steps over the 36 (A plane i, B plane s-i) pairs; the
-// accumulators are flushed to plane s whenever s changes.  Operand tiles go global -> LDS with
-// global_load_lds (16 B per lane, no VGPR staging) into two 64 KiB buffers: the loads of step t+1 are
-// in flight while step t is multiplied.  An LDS-DMA wave-instruction writes 1 KiB linearly (8 rows of
-// 128 B), so the bank swizzle is applied to the per-lane SOURCE address and undone on the ds_read:
-// 16-byte chunk c of row r lives at chunk position c ^ ((r >> 1) & 7), which puts the 16 rows a
-// ds_read_b128 lane group touches on 16 different 16-byte bank slots.
-constexpr u32 TM = 256, TN = 256, TK = 128;
-__global__ __launch_bounds__(512) void limb_gemm256_kernel(const i8 *__restrict__ Apl, const i8 *__restrict__ Bpl,
-                                                           i32 *__restrict__ Cpl, u32 Mp, u32 Np, u32 Kp, u32 tiles_m,
-                                                           u32 tiles_n) {
-    __shared__ __attribute__((aligned(1024))) i8 lds[2 * (TM + TN) * TK]; // 128 KiB
+    __shared__ __attribute__((aligned(1024))) i8 lds[2 * STAGE_BYTES]; // 96 KiB
     const u32 tid = threadIdx.x, lane = tid & 63;
     const u32 wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const u32 wm = wid >> 2, wn = wid & 3, lr = lane & 31, lh = lane >> 5;
+    const u32 wm = wid >> 1, wn = wid & 1, lr = lane & 31, lh = lane >> 5;
 
+    // XCD-aware tile order.  Workgroups b, b+8, b+16, .. share an XCD and its L2: give each XCD one
+    // contiguous run of tiles, and inside a run walk 4-row groups column by column so that the tiles in
+    // flight together form a compact rectangle that re-uses the same A row panels and B column panels.
     const u32 nwg = tiles_m * tiles_n;
     const u32 bid = blockIdx.x;
     const u32 qq = nwg / 8, rem = nwg % 8, xcd = bid % 8;
     const u32 swz = (xcd < rem ? xcd * (qq + 1) : rem * (qq + 1) + (xcd - rem) * qq) + bid / 8;
-    const u32 tm = swz / tiles_n, tn = swz % tiles_n;
+    const u32 GM = 4;
+    const u32 per_group = GM * tiles_n;
+    const u32 group = swz / per_group, in_group = swz % per_group;
+    const u32 first_m = group * GM;
+    const u32 gsz = (tiles_m - first_m < GM) ? tiles_m - first_m : GM;
+    const u32 tm = first_m + in_group % gsz, tn = in_group / gsz;
 
-    const u64 strideA = (u64)Mp * Kp, strideB = (u64)Np * Kp, strideC = (u64)Mp * Np;
-    const i8 *Ablk = Apl + (u64)tm * TM * Kp;
-    const i8 *Bblk = Bpl + (u64)tn * TN * Kp;
-
-    // staging: wave w issues 4 A pieces and 4 B pieces per step; piece p = 4w+q covers rows 8p..8p+7
-    u32 goff[4];
+    // ---- staging plan: 48 pieces of 1 KiB per step, 6 per wave.  Pieces 0..31: A limb p/4, rows 32*(p%4)..;
+    // pieces 32..47: B limb (p-32)/2, rows 32*((p-32)%2)..
+    const u32 lrow = lane >> 1;
+    const u32 lsrc = lrow * RK + (((lane & 1) ^ ((lrow >> 3) & 1)) << 4); // swizzled source offset inside a piece
+    const i8 *gsrc[6];
+    u32 gstep[6], ldst[6];
 #pragma unroll
-    for (u32 q = 0; q < 4; q++) {
-        const u32 row = (wid * 4 + q) * 8 + (lane >> 3);
-        const u32 ch = (lane & 7) ^ ((row >> 1) & 7);
-        goff[q] = row * Kp + ch * 16;
+    for (u32 q = 0; q < 6; q++) {
+        const u32 p = wid * 6 + q;
+        if (p < 32) {
+            const u32 limb = p >> 2, quarter = p & 3;
+            gsrc[q] = Apl + ((u64)limb * nkb * Mp + (u64)tm * RM + quarter * 32) * RK + lsrc;
+            gstep[q] = Mp * RK;
+            ldst[q] = limb * (RM * RK) + quarter * 1024;
+        } else {
+            const u32 limb = (p - 32) >> 1, half = (p - 32) & 1;
+            gsrc[q] = Bpl + ((u64)limb * nkb * Np + (u64)tn * RN + half * 32) * RK + lsrc;
+            gstep[q] = Np * RK;
+            ldst[q] = 8 * RM * RK + limb * (RN * RK) + half * 1024;
+        }
     }
-    // fragment reads: row (within the wave's 128 / 64 rows) lr + 32*tile; the swizzle term only depends on lr
-    const u32 rsw = (lr >> 1) & 7;
-    const u32 a_row_off = (wm * 128 + lr) * TK, b_row_off = (wn * 64 + lr) * TK;
-
-    const u32 nk = Kp / TK;
-    const u32 T = 36 * nk;
-
-    auto stage = [&](u32 buf, u32 pi, u32 pj, u32 kt) {
-        const i8 *Ap = Ablk + pi * strideA + kt * TK;
-        const i8 *Bp = Bblk + pj * strideB + kt * TK;
-        i8 *la = lds + buf * ((TM + TN) * TK) + wid * 4096;
-        i8 *lb = la + TM * TK;
+    auto stage = [&](u32 buf) {
 #pragma unroll
-        for (u32 q = 0; q < 4; q++) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(Ap + goff[q]),
-                                             (__attribute__((address_space(3))) void *)(la + q * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(Bp + goff[q]),
-                                             (__attribute__((address_space(3))) void *)(lb + q * 1024), 16, 0, 0);
+        for (u32 q = 0; q < 6; q++) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc[q],
+                                             (__attribute__((address_space(3))) void *)(lds + buf * STAGE_BYTES + ldst[q]),
+                                             16, 0, 0);
+            gsrc[q] += gstep[q];
         }
     };
 
-    v16i acc[4][2];
-#pragma unroll
-    for (int a = 0; a < 4; a++)
-#pragma unroll
-        for (int b = 0; b < 2; b++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[a][b][r] = 0;
+    // ---- fragment addresses (the swizzle term only depends on the lane)
+    const u32 fsw = (lh ^ ((lr >> 3) & 1)) << 4;
+    const u32 a_off = (wm * 32 + lr) * RK + fsw;
+    const u32 b_off = 8 * RM * RK + (wn * 32 + lr) * RK + fsw;
 
-    u32 ps = 0, pi = 0, pkt = 0; // tile being prefetched
-    u32 cs = 0, ci = 0, ckt = 0; // tile being multiplied
-    stage(0, 0, 0, 0);
+    v16i acc[8];
+#pragma unroll
+    for (int s = 0; s < 8; s++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[s][r] = 0;
+
+    if (ABL != 2) stage(0);
     __syncthreads();
     u32 cur = 0;
-    for (u32 t = 0; t < T; t++) {
-        if (t + 1 < T) {
-            if (++pkt == nk) {
-                pkt = 0;
-                if (pi == ps) {
-                    ps++;
-                    pi = 0;
-                } else {
-                    pi++;
-                }
-            }
-            stage(cur ^ 1, pi, ps - pi, pkt);
-        }
-        const i8 *la = lds + cur * ((TM + TN) * TK);
-        const i8 *lb = la + TM * TK;
+    for (u32 kb = 0; kb < nkb; kb++) {
+        if (kb + 1 < nkb && ABL != 2) stage(cur ^ 1);
+        if (ABL != 1) {
+            const i8 *base = lds + cur * STAGE_BYTES;
+            v4i a[8], b[8];
 #pragma unroll
-        for (u32 kk = 0; kk < TK / 32; kk++) {
-            const u32 coff = ((2 * kk + lh) ^ rsw) << 4;
-            v4i a[4], b[2];
+            for (u32 i = 0; i < 8; i++) a[i] = *(const v4i *)(base + a_off + i * (RM * RK));
 #pragma unroll
-            for (u32 mi = 0; mi < 4; mi++) a[mi] = *(const v4i *)(la + a_row_off + mi * 32 * TK + coff);
+            for (u32 j = 0; j < 8; j++) b[j] = *(const v4i *)(base + b_off + j * (RN * RK));
 #pragma unroll
-            for (u32 ni = 0; ni < 2; ni++) b[ni] = *(const v4i *)(lb + b_row_off + ni * 32 * TK + coff);
+            for (u32 i = 0; i < 8; i++)
 #pragma unroll
-            for (u32 mi = 0; mi < 4; mi++)
-#pragma unroll
-                for (u32 ni = 0; ni < 2; ni++)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
-        }
-        // last step of this s: flush the accumulators to plane s
-        const bool last_k = (ckt + 1 == nk);
-        if (last_k && ci == cs) {
-            i32 *Cs = Cpl + cs * strideC;
-#pragma unroll
-            for (u32 mi = 0; mi < 4; mi++)
-#pragma unroll
-                for (u32 ni = 0; ni < 2; ni++)
-#pragma unroll
-                    for (u32 r = 0; r < 16; r++) {
-                        const u32 row = tm * TM + wm * 128 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                        const u32 col = tn * TN + wn * 64 + ni * 32 + lr;
-                        Cs[(u64)row * Np + col] = acc[mi][ni][r];
-                        acc[mi][ni][r] = 0;
-                    }
-        }
-        if (last_k) {
-            ckt = 0;
-            if (ci == cs) {
-                cs++;
-                ci = 0;
-            } else {
-                ci++;
-            }
-        } else {
-            ckt++;
+                for (u32 j = 0; j + i < 8; j++)
+                    acc[i + j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[i], b[j], acc[i + j], 0, 0, 0);
         }
         __syncthreads(); // drains this step's LDS-DMA (vmcnt) and the fragment reads before the buffers swap
         cur ^= 1;
+    }
+
+    const u64 strideC = (u64)Mp * Np;
+    const u32 col = tn * RN + wn * 32 + lr;
+    const u32 row0 = tm * RM + wm * 32 + 4 * lh;
+#pragma unroll
+    for (u32 s = 0; s < 8; s++) {
+        i32 *Cs = Cpl + s * strideC + col;
+#pragma unroll
+        for (u32 r = 0; r < 16; r++) Cs[(u64)(row0 + (r & 3) + 8 * (r >> 2)) * Np] = acc[s][r];
     }
 }
 
@@ -320,16 +231,13 @@ inline u64 round_up(u64 a, u64 b) { return ceil_div(a, b) * b; }
 // K chunking: per accumulation chunk (all parts concatenated) 8 * Kc * 2^14 must stay below 2^31
 static u64 part_chunk_len(int nparts, u64 l) {
     const u64 max_kc = 8192;
-    u64 lc = round_up(l, BK);
-    while ((u64)nparts * lc > max_kc && lc > BK) lc = round_up(lc / 2, BK);
+    u64 lc = round_up(l, KPAD);
+    while ((u64)nparts * lc > max_kc && lc > KPAD) lc = round_up(lc / 2, KPAD);
     return lc;
 }
-// block tile edge: the 256-square LDS-DMA kernel for large outputs, the 128-square one otherwise
-static u64 tile_edge(u64 r, u64 c) { return (r >= 512 && c >= 512) ? TM : BM; }
 
 u64 ring_gemm_ws_bytes(int nparts, u64 r, u64 l, u64 c) {
-    const u64 te = tile_edge(r, c);
-    const u64 Mp = round_up(r, te), Np = round_up(c, te), Kp = (u64)nparts * part_chunk_len(nparts, l);
+    const u64 Mp = round_up(r, RM), Np = round_up(c, RM), Kp = (u64)nparts * part_chunk_len(nparts, l);
     const u64 bytesA = 8 * Mp * Kp, bytesB = 8 * Np * Kp, bytesC = 8 * Mp * Np * 4;
     return ((bytesA + 255) & ~255ull) + ((bytesB + 255) & ~255ull) + ((bytesC + 255) & ~255ull);
 }
@@ -340,8 +248,8 @@ int ring_gemm_parts(mpcx_ctx *ctx, const GemmPart *parts, int nparts, u64 r, u64
                  (unsigned long long)l, (unsigned long long)c);
     MPCX_REQUIRE(r < (1u << 30) && c < (1u << 30) && l < (1u << 30), "ring gemm: dimension too large");
     MPCX_REQUIRE(nparts >= 1 && nparts <= 8, "ring gemm: bad part count");
-    const u64 te = tile_edge(r, c);
-    const u64 Mp = round_up(r, te), Np = round_up(c, te);
+    // rows of both operands are padded to 128 (the split kernel works on 64-row tiles, the A tile is 128 rows)
+    const u64 Mp = round_up(r, RM), Np = round_up(c, RM);
     const u64 lc = part_chunk_len(nparts, l); // per-part chunk length along l
     const u64 Kp = (u64)nparts * lc;
     MPCX_REQUIRE(Kp <= 8192, "ring gemm: cannot chunk K");
@@ -351,9 +259,11 @@ int ring_gemm_parts(mpcx_ctx *ctx, const GemmPart *parts, int nparts, u64 r, u64
     i8 *Apl = (i8 *)ws;
     i8 *Bpl = Apl + ((bytesA + 255) & ~255ull);
     i32 *Cpl = (i32 *)(Bpl + ((bytesB + 255) & ~255ull));
-    const u32 tiles_m = (u32)(Mp / te), tiles_n = (u32)(Np / te);
+    const u32 tiles_m = (u32)(Mp / RM), tiles_n = (u32)(Np / RN);
+    const u32 nkb = (u32)(Kp / RK);
     const u64 soA = layA ? 1 : l, skA = layA ? r : 1; // A(o=row, k)
     const u64 soB = layB ? l : 1, skB = layB ? 1 : c; // B(o=col, k)
+    static const int abl = getenv("MPCX_GEMM_ABLATE") ? atoi(getenv("MPCX_GEMM_ABLATE")) : 0;
     int first = 1;
     for (u64 kb = 0; kb < l; kb += lc) {
         const u64 klen = (l - kb < lc) ? l - kb : lc;
@@ -369,12 +279,16 @@ int ring_gemm_parts(mpcx_ctx *ctx, const GemmPart *parts, int nparts, u64 r, u64
         }
         {
             ProfScope ps(ctx, PROF_GEMM);
-            if (te == TM)
-                hipLaunchKernelGGL(limb_gemm256_kernel, dim3(tiles_m * tiles_n), dim3(512), 0, ctx->stream, Apl, Bpl,
-                                   Cpl, (u32)Mp, (u32)Np, (u32)Kp, tiles_m, tiles_n);
+            const dim3 grid(tiles_m * tiles_n), block(512);
+            if (abl == 1)
+                hipLaunchKernelGGL(limb_gemm_kernel<1>, grid, block, 0, ctx->stream, Apl, Bpl, Cpl, (u32)Mp, (u32)Np, nkb,
+                                   tiles_m, tiles_n);
+            else if (abl == 2)
+                hipLaunchKernelGGL(limb_gemm_kernel<2>, grid, block, 0, ctx->stream, Apl, Bpl, Cpl, (u32)Mp, (u32)Np, nkb,
+                                   tiles_m, tiles_n);
             else
-                hipLaunchKernelGGL(limb_gemm_kernel, dim3(tiles_m * tiles_n), dim3(256), 0, ctx->stream, Apl, Bpl, Cpl,
-                                   (u32)Mp, (u32)Np, (u32)Kp, tiles_m, tiles_n);
+                hipLaunchKernelGGL(limb_gemm_kernel<0>, grid, block, 0, ctx->stream, Apl, Bpl, Cpl, (u32)Mp, (u32)Np, nkb,
+                                   tiles_m, tiles_n);
         }
         const u64 total = r * c;
         const u32 grid = (u32)(ceil_div(total, 256) < 4096 ? ceil_div(total, 256) : 4096);
