@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void split_limbs_kernel(const u64 *__restrict_
 // byte feeds 192 multiply-adds (a plain one-accumulator 256x256 tiling feeds 128), and the accumulators
 // are written out once, after the whole K loop.
 //
-// Staging is LDS-DMA (global_load_lds, 16 B per lane, two 48 KiB buffers: step t+1 lands while step t
+// Staging is LDS-DMA (global_load_lds, 16 B per lane) into two 48 KiB buffers (step t+1 lands while step t
 // is multiplied).  A DMA wave-instruction writes 1 KiB linearly = 32 rows x 32 B, so the bank swizzle
 // is applied to the per-lane SOURCE address and undone on the ds_read: 16-byte half h of row r is kept
 // at half h ^ ((r >> 3) & 1), which spreads the 16 rows of a ds_read_b128 lane group over all 64 banks.
@@ -92,7 +92,7 @@ template <int ABL>
 __global__ __launch_bounds__(512) void limb_gemm_kernel(const i8 *__restrict__ Apl, const i8 *__restrict__ Bpl,
                                                         i32 *__restrict__ Cpl, u32 Mp, u32 Np, u32 nkb, u32 tiles_m,
                                                         u32 tiles_n) {
-    __shared__ __attribute__((aligned(1024))) i8 lds[2 * STAGE_BYTES]; // 96 KiB
+    __shared__ __attribute__((aligned(1024))) i8 lds[2 * STAGE_BYTES]; // 96 KiB: two staging buffers
     const u32 tid = threadIdx.x, lane = tid & 63;
     const u32 wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const u32 wm = wid >> 1, wn = wid & 1, lr = lane & 31, lh = lane >> 5;
@@ -153,27 +153,63 @@ __global__ __launch_bounds__(512) void limb_gemm_kernel(const i8 *__restrict__ A
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[s][r] = 0;
 
-    if (ABL != 2) stage(0);
-    __syncthreads();
+    // Software pipeline with ONE barrier per K step, placed in the middle of the step's MFMA stream:
+    //   first part : MFMAs with A limbs 0..3 (26 of 36) while the remaining A fragments of this step are read;
+    //   barrier    : by now every wave has read ALL its fragments of step kb (they sit in registers) and its
+    //                DMA pieces of step kb+1 have landed (vmcnt(0)), so after the barrier the buffer of step kb
+    //                is free and step kb+1 is visible to everyone;
+    //   second part: re-fill the freed buffer with step kb+2, read the first fragments of step kb+1, and issue
+    //                the last 10 MFMAs (A limbs 4..7) of step kb from registers.
+    // The matrix pipe therefore never waits for LDS right after a barrier.
+    auto rdA = [&](u32 buf, u32 i) { return *(const v4i *)(lds + buf * STAGE_BYTES + a_off + i * (RM * RK)); };
+    auto rdB = [&](u32 buf, u32 j) { return *(const v4i *)(lds + buf * STAGE_BYTES + b_off + j * (RN * RK)); };
+    v4i b[8], a0;
+    if (ABL != 2) {
+        stage(0);
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        if (nkb > 1) stage(1);
+    }
+#pragma unroll
+    for (u32 j = 0; j < 8; j++) b[j] = rdB(0, j);
+    a0 = rdA(0, 0);
     u32 cur = 0;
     for (u32 kb = 0; kb < nkb; kb++) {
-        if (kb + 1 < nkb && ABL != 2) stage(cur ^ 1);
+        v4i a[8];
+        a[0] = a0;
         if (ABL != 1) {
-            const i8 *base = lds + cur * STAGE_BYTES;
-            v4i a[8], b[8];
 #pragma unroll
-            for (u32 i = 0; i < 8; i++) a[i] = *(const v4i *)(base + a_off + i * (RM * RK));
+            for (u32 i = 1; i < 8; i++) a[i] = rdA(cur, i);
 #pragma unroll
-            for (u32 j = 0; j < 8; j++) b[j] = *(const v4i *)(base + b_off + j * (RN * RK));
-#pragma unroll
-            for (u32 i = 0; i < 8; i++)
+            for (u32 i = 0; i < 4; i++)
 #pragma unroll
                 for (u32 j = 0; j + i < 8; j++)
                     acc[i + j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[i], b[j], acc[i + j], 0, 0, 0);
         }
-        __syncthreads(); // drains this step's LDS-DMA (vmcnt) and the fragment reads before the buffers swap
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (kb + 2 < nkb && ABL != 2) stage(cur);
+        v4i bn[8], an0;
+        if (kb + 1 < nkb) {
+#pragma unroll
+            for (u32 j = 0; j < 8; j++) bn[j] = rdB(cur ^ 1, j);
+            an0 = rdA(cur ^ 1, 0);
+        } else {
+#pragma unroll
+            for (u32 j = 0; j < 8; j++) bn[j] = b[j];
+            an0 = a0;
+        }
+        if (ABL != 1) {
+#pragma unroll
+            for (u32 i = 4; i < 8; i++)
+#pragma unroll
+                for (u32 j = 0; j + i < 8; j++)
+                    acc[i + j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[i], b[j], acc[i + j], 0, 0, 0);
+        }
+#pragma unroll
+        for (u32 j = 0; j < 8; j++) b[j] = bn[j];
+        a0 = an0;
         cur ^= 1;
     }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 
     const u64 strideC = (u64)Mp * Np;
     const u32 col = tn * RN + wn * 32 + lr;
