@@ -66,6 +66,12 @@ int mpcx_prg_fill_buff(mpcx_ctx *ctx, uint64_t seed, uint64_t lcg, uint64_t firs
                        int8_t *bools);
 /* pops first_pop .. first_pop+count of pop_int64()                                         (:34-37) */
 int mpcx_prg_fill_pop(mpcx_ctx *ctx, uint64_t seed, uint64_t lcg, uint64_t first_pop, uint64_t count, int64_t *out);
+/* The reference fills int_buff once, in the PRgenerator constructor (:27-32), and privateCompare,
+ * shareConvert and msb_L_1 afterwards only read it (SecurennEngine.cpp:523-534, :838-839, :922-923).  The
+ * library's counterpart: the "(uint16)int_buff[i] % 67" byte slices those calls consume are generated on
+ * first use and kept on the device, up to max_bytes per context (default 4 GiB; 64 bytes per element and
+ * slice; least recently used slices are dropped; 0 = regenerate on every call). */
+int mpcx_set_rand_cache(mpcx_ctx *ctx, uint64_t max_bytes);
 /* host-side: the (seed, lcg, hash) members of a generator that has popped pop_index words  (:12-14) */
 int mpcx_prg_state_at_pop(mpcx_ctx *ctx, uint64_t seed, uint64_t lcg, uint64_t pop_index, uint64_t state_out[3]);
 

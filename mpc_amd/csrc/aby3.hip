@@ -17,119 +17,111 @@ template <class F> int ew_launch(mpcx_ctx *ctx, u64 n, F f) {
     return 0;
 }
 
-// mask of the carry-tree positions that are still live when pairs are `s` bits apart:
-// bits at multiples of 2s
-__device__ inline u64 even_mask(u32 s) {
-    switch (s) {
-    case 1: return 0x5555555555555555ull;
-    case 2: return 0x1111111111111111ull;
-    case 4: return 0x0101010101010101ull;
-    case 8: return 0x0001000100010001ull;
-    case 16: return 0x0000000100000001ull;
-    default: return 1ull;
-    }
+// mask of the carry-tree positions that are still live when pairs are S bits apart: bits at multiples of 2S
+template <u32 S> __device__ constexpr u64 even_mask() {
+    return S == 1 ? 0x5555555555555555ull
+         : S == 2 ? 0x1111111111111111ull
+         : S == 4 ? 0x0101010101010101ull
+         : S == 8 ? 0x0001000100010001ull
+         : S == 16 ? 0x0000000100000001ull
+                   : 1ull;
 }
 // this round's product share of the element (ABY3Engine.cpp:397-414 + :253-256) on packed words:
-// even result bits pair (P[2m+1], G[2m]), odd result bits pair (P[2m+1], P[2m]); bit m sits at 2*m*s.
-__device__ inline void msb_products(u64 g0, u64 g1, u64 p0, u64 p1, u32 s, u64 &re, u64 &ro) {
-    const u64 E = even_mask(s);
-    const u64 po0 = (p0 >> s) & E, po1 = (p1 >> s) & E;
+// even result bits pair (P[2m+1], G[2m]), odd result bits pair (P[2m+1], P[2m]); bit m sits at 2*m*S.
+template <u32 S> __device__ inline void msb_products(u64 g0, u64 g1, u64 p0, u64 p1, u64 &re, u64 &ro) {
+    constexpr u64 E = even_mask<S>();
+    const u64 po0 = (p0 >> S) & E, po1 = (p1 >> S) & E;
     const u64 ge0 = g0 & E, ge1 = g1 & E, pe0 = p0 & E, pe1 = p1 & E;
     re = (po0 & ge0) ^ (po1 & ge0) ^ (po0 & ge1);
     ro = (po0 & pe0) ^ (po1 & pe0) ^ (po0 & pe1);
 }
-// 8 wire bytes: pairs m = m0..m0+3 -> byte 2j = even bit, byte 2j+1 = odd bit
-__device__ inline u64 msb_pack8(u64 re, u64 ro, u32 m0, u32 s, u32 npairs) {
+
+// Work split of one round with `TEMP` pairs per element (2*TEMP wire bytes per element): an element is
+// handled by G adjacent lanes, each owning NP pairs = 2*NP consecutive wire bytes.
+template <u32 TEMP> struct MsbGeom {
+    static constexpr u32 S = 32 / TEMP;              // distance of the two bits of a pair in the packed word
+    static constexpr u32 G = TEMP >= 4 ? TEMP / 4 : 1; // lanes per element
+    static constexpr u32 NP = TEMP / G;               // pairs per lane: 4, 2 or 1
+};
+// wire bytes of pairs m0 .. m0+NP-1: byte 2j = even bit, byte 2j+1 = odd bit
+template <u32 TEMP> __device__ inline u64 msb_pack(u64 re, u64 ro, u32 m0) {
+    using Ge = MsbGeom<TEMP>;
     u64 w = 0;
 #pragma unroll
-    for (u32 j = 0; j < 4; j++) {
-        if (j < npairs) {
-            const u32 pos = 2 * (m0 + j) * s;
-            w |= ((re >> pos) & 1ull) << (16 * j);
-            w |= ((ro >> pos) & 1ull) << (16 * j + 8);
-        }
+    for (u32 j = 0; j < Ge::NP; j++) {
+        const u32 pos = 2 * (m0 + j) * Ge::S;
+        w |= ((re >> pos) & 1ull) << (16 * j);
+        w |= ((ro >> pos) & 1ull) << (16 * j + 8);
     }
     return w;
 }
-__device__ inline void msb_unpack8(u64 w, u32 m0, u32 s, u32 npairs, u64 &re, u64 &ro) {
+template <u32 TEMP> __device__ inline void msb_unpack(u64 w, u32 m0, u64 &re, u64 &ro) {
+    using Ge = MsbGeom<TEMP>;
 #pragma unroll
-    for (u32 j = 0; j < 4; j++) {
-        if (j < npairs) {
-            const u32 pos = 2 * (m0 + j) * s;
-            re |= ((w >> (16 * j)) & 1ull) << pos;
-            ro |= ((w >> (16 * j + 8)) & 1ull) << pos;
-        }
+    for (u32 j = 0; j < Ge::NP; j++) {
+        const u32 pos = 2 * (m0 + j) * Ge::S;
+        re |= ((w >> (16 * j)) & 1ull) << pos;
+        ro |= ((w >> (16 * j + 8)) & 1ull) << pos;
     }
 }
+template <u32 NP> __device__ inline void msb_store_piece(u8 *msg, u64 c, u64 w) {
+    if (NP == 4)
+        *(u64 *)(msg + 8 * c) = w;
+    else if (NP == 2)
+        *(u32 *)(msg + 4 * c) = (u32)w;
+    else
+        *(u16 *)(msg + 2 * c) = (u16)w;
+}
+template <u32 NP> __device__ inline u64 msb_load_piece(const u8 *msg, u64 c) {
+    if (NP == 4) return *(const u64 *)(msg + 8 * c);
+    if (NP == 2) return (u64) * (const u32 *)(msg + 4 * c);
+    return (u64) * (const u16 *)(msg + 2 * c);
+}
 
-// temp >= 4: temp/4 lanes per element, each writes one 8-byte piece of the element's 2*temp bytes
-__global__ __launch_bounds__(256) void msb_round_pre_wide(u64 *__restrict__ st, u64 n, u32 temp, u64 *__restrict__ msg) {
-    const u32 s = 32 / temp, g = temp / 4;
-    const u64 chunks = n * g;
-    for (u64 c = (u64)blockIdx.x * 256 + threadIdx.x; c < chunks; c += (u64)gridDim.x * 256) {
-        const u64 k = c / g;
-        const u32 q = (u32)(c - k * g);
+// before the round: every lane computes the element's product share and writes its piece of the message;
+// the element's first lane then advances share 0 of the state (:424-425 with i = 0): G' = res_even ^ G_odd,
+// P' = res_odd.  The G lanes of an element sit in one wavefront and all of them load the state before the
+// first lane stores it.
+template <u32 TEMP> __global__ __launch_bounds__(256) void msb_round_pre_kernel(u64 *st, u64 n, u8 *__restrict__ msg) {
+    using Ge = MsbGeom<TEMP>;
+    const u64 pieces = n * Ge::G;
+    for (u64 c = (u64)blockIdx.x * 256 + threadIdx.x; c < pieces; c += (u64)gridDim.x * 256) {
+        const u64 k = c / Ge::G;
+        const u32 q = (u32)(c % Ge::G);
         const u64 g0 = st[k], g1 = st[n + k], p0 = st[2 * n + k], p1 = st[3 * n + k];
         u64 re, ro;
-        msb_products(g0, g1, p0, p1, s, re, ro);
-        msg[c] = msb_pack8(re, ro, 4 * q, s, 4);
-        if (q == 0) { // advance share 0 (:424-425): G' = res_even ^ G_odd, P' = res_odd
-            st[k] = re ^ ((g0 >> s) & even_mask(s));
+        msb_products<Ge::S>(g0, g1, p0, p1, re, ro);
+        msb_store_piece<Ge::NP>(msg, c, msb_pack<TEMP>(re, ro, Ge::NP * q));
+        if (q == 0) {
+            st[k] = re ^ ((g0 >> Ge::S) & even_mask<Ge::S>());
             st[2 * n + k] = ro;
         }
     }
 }
-// temp in {1,2}: one lane per element, 2*temp bytes each
-__global__ __launch_bounds__(256) void msb_round_pre_narrow(u64 *__restrict__ st, u64 n, u32 temp, u8 *__restrict__ msg) {
-    const u32 s = 32 / temp;
-    for (u64 k = (u64)blockIdx.x * 256 + threadIdx.x; k < n; k += (u64)gridDim.x * 256) {
-        const u64 g0 = st[k], g1 = st[n + k], p0 = st[2 * n + k], p1 = st[3 * n + k];
-        u64 re, ro;
-        msb_products(g0, g1, p0, p1, s, re, ro);
-        const u64 w = msb_pack8(re, ro, 0, s, temp);
-        if (temp == 2)
-            *(u32 *)(msg + 4 * k) = (u32)w;
-        else
-            *(u16 *)(msg + 2 * k) = (u16)w;
-        st[k] = re ^ ((g0 >> s) & even_mask(s));
-        st[2 * n + k] = ro;
-    }
-}
-// share 1 after the round (:416-428 with i = 1): the temp/4 lanes of an element OR their pieces together
-__global__ __launch_bounds__(256) void msb_round_post_wide(u64 *__restrict__ st, u64 n, u32 temp,
-                                                           const u64 *__restrict__ msg) {
-    const u32 s = 32 / temp, g = temp / 4;
-    const u64 chunks = n * g;
-    // every lane of a group must reach the shuffles: iterate on a group-aligned, wave-uniform trip count
+// after the round (:416-428 with i = 1): msg = result[1] from the next party; the G lanes of an element OR
+// their pieces together and the first lane advances share 1 of the state.
+template <u32 TEMP> __global__ __launch_bounds__(256) void msb_round_post_kernel(u64 *st, u64 n, const u8 *__restrict__ msg) {
+    using Ge = MsbGeom<TEMP>;
+    const u64 pieces = n * Ge::G;
+    // every lane of a group must reach the shuffles: iterate on a wave-uniform trip count
     const u64 stride = (u64)gridDim.x * 256;
-    for (u64 base = (u64)blockIdx.x * 256; base < chunks; base += stride) {
+    for (u64 base = (u64)blockIdx.x * 256; base < pieces; base += stride) {
         const u64 c = base + threadIdx.x;
-        const bool live = c < chunks;
-        const u64 k = live ? c / g : 0;
-        const u32 q = live ? (u32)(c - k * g) : 0;
+        const bool live = c < pieces; // pieces is a multiple of G, so a group is all-live or all-dead
+        const u64 k = live ? c / Ge::G : 0;
+        const u32 q = (u32)(c % Ge::G);
         u64 re = 0, ro = 0;
-        if (live) msb_unpack8(msg[c], 4 * q, s, 4, re, ro);
-        for (u32 d = 1; d < g; d <<= 1) { // groups are aligned runs of g lanes (g divides 64 and 256)
-            re |= __shfl_xor(re, d);
-            ro |= __shfl_xor(ro, d);
+        if (live) msb_unpack<TEMP>(msb_load_piece<Ge::NP>(msg, c), Ge::NP * q, re, ro);
+#pragma unroll
+        for (u32 d = 1; d < Ge::G; d <<= 1) { // groups are aligned runs of G lanes (G divides 64)
+            re |= __shfl_xor(re, (int)d, (int)Ge::G);
+            ro |= __shfl_xor(ro, (int)d, (int)Ge::G);
         }
         if (live && q == 0) {
             const u64 g1 = st[n + k];
-            st[n + k] = re ^ ((g1 >> s) & even_mask(s));
+            st[n + k] = re ^ ((g1 >> Ge::S) & even_mask<Ge::S>());
             st[3 * n + k] = ro;
         }
-    }
-}
-__global__ __launch_bounds__(256) void msb_round_post_narrow(u64 *__restrict__ st, u64 n, u32 temp,
-                                                             const u8 *__restrict__ msg) {
-    const u32 s = 32 / temp;
-    for (u64 k = (u64)blockIdx.x * 256 + threadIdx.x; k < n; k += (u64)gridDim.x * 256) {
-        const u64 w = (temp == 2) ? (u64) * (const u32 *)(msg + 4 * k) : (u64) * (const u16 *)(msg + 2 * k);
-        u64 re = 0, ro = 0;
-        msb_unpack8(w, 0, s, temp, re, ro);
-        const u64 g1 = st[n + k];
-        st[n + k] = re ^ ((g1 >> s) & even_mask(s));
-        st[3 * n + k] = ro;
     }
 }
 
@@ -307,12 +299,15 @@ int mpcx_aby3_msb_round_pre(mpcx_ctx *ctx, uint64_t *state, uint64_t n, uint64_t
                  "mpcx_aby3_msb_round_pre: temp must be one of 32,16,8,4,2,1");
     MPCX_REQUIRE(((uintptr_t)msg_out & 7) == 0, "mpcx_aby3_msb_round_pre: msg_out must be 8-byte aligned");
     ProfScope ps(ctx, PROF_MSB);
-    if (temp >= 4)
-        hipLaunchKernelGGL(msb_round_pre_wide, dim3(grid_for(n * (temp / 4))), dim3(256), 0, ctx->stream, state, n,
-                           (u32)temp, (u64 *)msg_out);
-    else
-        hipLaunchKernelGGL(msb_round_pre_narrow, dim3(grid_for(n)), dim3(256), 0, ctx->stream, state, n, (u32)temp,
-                           (u8 *)msg_out);
+#define MSB_PRE(T)                                                                                                     \
+    case T:                                                                                                            \
+        hipLaunchKernelGGL(msb_round_pre_kernel<T>, dim3(grid_for(n * MsbGeom<T>::G)), dim3(256), 0, ctx->stream, state, \
+                           n, (u8 *)msg_out);                                                                          \
+        break;
+    switch (temp) {
+        MSB_PRE(32) MSB_PRE(16) MSB_PRE(8) MSB_PRE(4) MSB_PRE(2) MSB_PRE(1)
+    }
+#undef MSB_PRE
     MPCX_LAUNCH_CHECK();
     return 0;
 }
@@ -323,12 +318,15 @@ int mpcx_aby3_msb_round_post(mpcx_ctx *ctx, uint64_t *state, uint64_t n, uint64_
                  "mpcx_aby3_msb_round_post: temp must be one of 32,16,8,4,2,1");
     MPCX_REQUIRE(((uintptr_t)msg_in & 7) == 0, "mpcx_aby3_msb_round_post: msg_in must be 8-byte aligned");
     ProfScope ps(ctx, PROF_MSB);
-    if (temp >= 4)
-        hipLaunchKernelGGL(msb_round_post_wide, dim3(grid_for(n * (temp / 4))), dim3(256), 0, ctx->stream, state, n,
-                           (u32)temp, (const u64 *)msg_in);
-    else
-        hipLaunchKernelGGL(msb_round_post_narrow, dim3(grid_for(n)), dim3(256), 0, ctx->stream, state, n, (u32)temp,
-                           (const u8 *)msg_in);
+#define MSB_POST(T)                                                                                                    \
+    case T:                                                                                                            \
+        hipLaunchKernelGGL(msb_round_post_kernel<T>, dim3(grid_for(n * MsbGeom<T>::G)), dim3(256), 0, ctx->stream,     \
+                           state, n, (const u8 *)msg_in);                                                              \
+        break;
+    switch (temp) {
+        MSB_POST(32) MSB_POST(16) MSB_POST(8) MSB_POST(4) MSB_POST(2) MSB_POST(1)
+    }
+#undef MSB_POST
     MPCX_LAUNCH_CHECK();
     return 0;
 }

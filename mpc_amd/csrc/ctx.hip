@@ -71,6 +71,7 @@ int mpcx_shutdown(mpcx_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->ws) (void)hipFree(ctx->ws);
+    prg_rand_cache_clear(ctx);
     for (auto &v : ctx->prof_ev)
         for (auto &p : v) {
             (void)hipEventDestroy(p.first);

@@ -37,6 +37,17 @@ struct mpcx_ctx {
     std::string err;
     void *ws = nullptr; // scratch workspace, grown on demand
     u64 ws_bytes = 0;
+    // Values derived from a generator's int_buff, kept on the device between calls.  The reference fills
+    // int_buff once in the PRgenerator constructor (utils/PRgenerator.cpp:27-32) and every later call only
+    // reads it; this cache is the counterpart for the slices a kernel consumes as bytes mod 67.
+    struct RandEntry {
+        u64 seed, lcg, first, count;
+        int mode;
+        u8 *dev;
+        u64 last_use;
+    };
+    std::vector<RandEntry> rand_cache;
+    u64 rand_bytes = 0, rand_cap = 4ull << 30, rand_tick = 0;
 };
 
 int mpcx_fail(mpcx_ctx *ctx, const char *fmt, ...);
@@ -84,6 +95,13 @@ struct ProfScope {
 // internal launchers used across translation units (all asynchronous on ctx->stream)
 int prg_fill_words(mpcx_ctx *ctx, u64 seed, u64 lcg, u64 t_first, u64 count, u64 stride, i64 *out, i8 *bools);
 int prg_fill_buff_mod67(mpcx_ctx *ctx, u64 seed, u64 lcg, u64 first, u64 count, int zero_to_one, u8 *out);
+// The same bytes through the context's cache: *out points at cached device memory.  Entries requested since
+// the caller last advanced ctx->rand_tick are never evicted, so a call bumps the tick once and may then hold
+// several slices.  A slice that does not fit the cache budget is generated at byte ws_offset of the context
+// workspace, which is grown to ws_total bytes (pass the same ws_total for every request of one call).
+int prg_buff_mod67_cached(mpcx_ctx *ctx, u64 seed, u64 lcg, u64 first, u64 count, int zero_to_one, u64 ws_total,
+                          u64 ws_offset, const u8 **out);
+void prg_rand_cache_clear(mpcx_ctx *ctx);
 static inline u64 ceil_div(u64 a, u64 b) { return (a + b - 1) / b; }
 
 // Z (+)= [A_1 | A_2 | ..] * [B_1 (+Bplus_1) ; B_2 ; ..] (+ add - sub): a ring product whose K dimension is the

@@ -162,7 +162,71 @@ int prg_fill_buff_mod67(mpcx_ctx *ctx, u64 seed, u64 lcg, u64 first, u64 count, 
     return prg_launch(ctx, seed, lcg, 2 * first, 2 * first + 2 * count - 1, zero_to_one ? 3 : 2, nullptr, out);
 }
 
+void prg_rand_cache_clear(mpcx_ctx *ctx) {
+    if (ctx->rand_cache.empty()) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &e : ctx->rand_cache) (void)hipFree(e.dev);
+    ctx->rand_cache.clear();
+    ctx->rand_bytes = 0;
+}
+
+int prg_buff_mod67_cached(mpcx_ctx *ctx, u64 seed, u64 lcg, u64 first, u64 count, int zero_to_one, u64 ws_total,
+                          u64 ws_offset, const u8 **out) {
+    const int mode = zero_to_one ? 3 : 2;
+    const u64 epoch = ctx->rand_tick; // entries touched in this epoch belong to the call in progress
+    for (auto &e : ctx->rand_cache)
+        if (e.seed == seed && e.lcg == lcg && e.mode == mode && e.first <= first && first + count <= e.first + e.count &&
+            (first - e.first) % 16 == 0) { // consumers read the bytes as aligned 8- and 16-byte words
+            e.last_use = epoch;
+            *out = e.dev + (first - e.first);
+            return 0;
+        }
+    bool fits = count <= ctx->rand_cap;
+    while (fits && ctx->rand_bytes + count > ctx->rand_cap) {
+        int victim = -1;
+        for (int i = 0; i < (int)ctx->rand_cache.size(); i++)
+            if (ctx->rand_cache[i].last_use != epoch && (victim < 0 || ctx->rand_cache[i].last_use < ctx->rand_cache[victim].last_use))
+                victim = i;
+        if (victim < 0) {
+            fits = false;
+            break;
+        }
+        MPCX_HIP(hipStreamSynchronize(ctx->stream)); // a kernel in flight may still read the victim
+        MPCX_HIP(hipFree(ctx->rand_cache[victim].dev));
+        ctx->rand_bytes -= ctx->rand_cache[victim].count;
+        ctx->rand_cache.erase(ctx->rand_cache.begin() + victim);
+    }
+    if (!fits) {
+        MPCX_REQUIRE(ws_offset + count <= ws_total, "prg_buff_mod67_cached: scratch range outside the workspace");
+        void *ws;
+        MPCX_TRY(mpcx_ws(ctx, ws_total, &ws));
+        u8 *fallback = (u8 *)ws + ws_offset;
+        MPCX_TRY(prg_fill_buff_mod67(ctx, seed, lcg, first, count, zero_to_one, fallback));
+        *out = fallback;
+        return 0;
+    }
+    u8 *dev = nullptr;
+    MPCX_HIP(hipSetDevice(ctx->device));
+    MPCX_HIP(hipMalloc((void **)&dev, count));
+    int rc = prg_fill_buff_mod67(ctx, seed, lcg, first, count, zero_to_one, dev);
+    if (rc) {
+        (void)hipFree(dev);
+        return rc;
+    }
+    ctx->rand_cache.push_back({seed, lcg, first, count, mode, dev, epoch});
+    ctx->rand_bytes += count;
+    *out = dev;
+    return 0;
+}
+
 extern "C" {
+
+int mpcx_set_rand_cache(mpcx_ctx *ctx, uint64_t max_bytes) {
+    if (max_bytes < ctx->rand_bytes) prg_rand_cache_clear(ctx);
+    ctx->rand_cap = max_bytes;
+    return 0;
+}
 
 int mpcx_prg_ckpt_build(mpcx_ctx *ctx, uint64_t seed, uint64_t lcg, uint64_t n_pops, uint64_t n_buff) {
     u64 t_end = 2 * n_buff;

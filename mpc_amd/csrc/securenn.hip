@@ -319,11 +319,10 @@ int mpcx_snn_pc_party(mpcx_ctx *ctx, int party, const uint16_t *xbits, const int
     MPCX_REQUIRE(xbits && beta && r && d_out, "mpcx_snn_pc_party: NULL pointer");
     MPCX_REQUIRE(i0 + n <= n_total, "mpcx_snn_pc_party: range outside the vector");
     MPCX_REQUIRE(((uintptr_t)xbits & 15) == 0 && ((uintptr_t)d_out & 15) == 0, "mpcx_snn_pc_party: xbits/d_out must be 16-byte aligned");
-    void *ws;
-    MPCX_TRY(mpcx_ws(ctx, 128 * n, &ws));
-    u8 *S = (u8 *)ws, *U = S + 64 * n;
-    MPCX_TRY(prg_fill_buff_mod67(ctx, seed01, 0, 64 * i0, 64 * n, 1, S));                // :523,525-529
-    MPCX_TRY(prg_fill_buff_mod67(ctx, seed01, 0, 64 * n_total + 64 * i0, 64 * n, 1, U)); // :524,530-534
+    const u8 *S, *U;
+    ctx->rand_tick++;
+    MPCX_TRY(prg_buff_mod67_cached(ctx, seed01, 0, 64 * i0, 64 * n, 1, 128 * n, 0, &S));                     // :523,525-529
+    MPCX_TRY(prg_buff_mod67_cached(ctx, seed01, 0, 64 * n_total + 64 * i0, 64 * n, 1, 128 * n, 64 * n, &U)); // :524,530-534
     ProfScope ps(ctx, PROF_PC_PARTY);
     hipLaunchKernelGGL(pc_party_kernel, dim3(grid_for(8 * n)), dim3(256), 0, ctx->stream, party, (const uint4 *)xbits, beta,
                        r, (const u64 *)S, (const u64 *)U, n, (uint4 *)d_out);
@@ -414,12 +413,14 @@ int mpcx_snn_sc_helper_split(mpcx_ctx *ctx, const int64_t *x0, const int64_t *x1
     MPCX_REQUIRE(x0 && x1 && xbits0 && delta0 && xbits1 && delta1, "mpcx_snn_sc_helper_split: NULL pointer");
     MPCX_REQUIRE(i0 + n <= n_total, "mpcx_snn_sc_helper_split: range outside the vector");
     MPCX_REQUIRE(((uintptr_t)xbits0 & 15) == 0 && ((uintptr_t)xbits1 & 15) == 0, "mpcx_snn_sc_helper_split: xbits must be 16-byte aligned");
+    // the cache request comes first: it may grow (and so move) the workspace the other pointers live in
+    const u8 *rnd;
+    ctx->rand_tick++;
+    MPCX_TRY(prg_buff_mod67_cached(ctx, seedS, 0, 64 * i0, 64 * n, 0, 80 * n, 16 * n, &rnd)); // :838-839
     void *ws;
-    MPCX_TRY(mpcx_ws(ctx, 80 * n, &ws));
+    MPCX_TRY(mpcx_ws(ctx, 16 * n, &ws));
     u64 *x = (u64 *)ws, *d0w = x + n;
-    u8 *rnd = (u8 *)(d0w + n);
     MPCX_TRY(prg_fill_words(ctx, seedS, 0, 2 * i0, n, 2, (i64 *)d0w, nullptr)); // :848
-    MPCX_TRY(prg_fill_buff_mod67(ctx, seedS, 0, 64 * i0, 64 * n, 0, rnd));       // :838-839
     const u64 *a = (const u64 *)x0, *b = (const u64 *)x1;
     MPCX_TRY(ew_launch(ctx, n, [=] __device__(u64 i) {
         const u64 xv = a[i] + b[i]; // :824
@@ -457,14 +458,15 @@ int mpcx_snn_msbl1_helper_deal(mpcx_ctx *ctx, uint64_t n_total, uint64_t i0, uin
     MPCX_REQUIRE(x0 && xlsb0 && xbits0 && x1 && xlsb1 && xbits1, "mpcx_snn_msbl1_helper_deal: NULL pointer");
     MPCX_REQUIRE(i0 + n <= n_total, "mpcx_snn_msbl1_helper_deal: range outside the vector");
     MPCX_REQUIRE(((uintptr_t)xbits0 & 15) == 0 && ((uintptr_t)xbits1 & 15) == 0, "mpcx_snn_msbl1_helper_deal: xbits must be 16-byte aligned");
+    const u8 *rnd;
+    ctx->rand_tick++;
+    MPCX_TRY(prg_buff_mod67_cached(ctx, seedS, 0, 3 * n_total + 64 * i0, 64 * n, 0, 96 * n, 32 * n, &rnd)); // :922-923
     void *ws;
-    MPCX_TRY(mpcx_ws(ctx, 96 * n, &ws));
+    MPCX_TRY(mpcx_ws(ctx, 32 * n, &ws));
     u64 *w0 = (u64 *)ws, *w1 = w0 + n, *w2 = w1 + n, *xv = w2 + n;
-    u8 *rnd = (u8 *)(xv + n);
     MPCX_TRY(prg_fill_words(ctx, seedS, 0, 2 * i0, n, 2, (i64 *)w0, nullptr));                  // :911
     MPCX_TRY(prg_fill_words(ctx, seedS, 0, 2 * (n_total + i0), n, 2, (i64 *)w1, nullptr));     // :913
     MPCX_TRY(prg_fill_words(ctx, seedS, 0, 2 * (2 * n_total + i0), n, 2, (i64 *)w2, nullptr)); // :917
-    MPCX_TRY(prg_fill_buff_mod67(ctx, seedS, 0, 3 * n_total + 64 * i0, 64 * n, 0, rnd));        // :922-923
     MPCX_TRY(ew_launch(ctx, n, [=] __device__(u64 i) {
         const u64 X0 = w0[i] % L_1, X1 = w1[i] % L_1; // :912,:914
         const u64 X = add_L_1(X0, X1);                // :915

@@ -50,6 +50,10 @@ class DeviceArray:
             ptr = p.value
         self.ptr = ptr
 
+    @property
+    def size(self):
+        return self.n
+
     def view(self, offset_elems, n, dtype=None):
         dt = np.dtype(dtype) if dtype is not None else self.dtype
         return DeviceArray(self.ctx, dt, n, ptr=self.ptr + offset_elems * self.dtype.itemsize, owner=self)

@@ -13,7 +13,9 @@ from oracle_lib import i8, i64, oracle, u16
 
 
 def _c(a, dt):
-    return None if a is None else np.ascontiguousarray(a, dtype=dt)
+    if a is None or hasattr(a, "ptr"):  # None, or a buffer already on the device
+        return a
+    return np.ascontiguousarray(a, dtype=dt)
 
 
 class OracleBackend:
@@ -558,3 +560,87 @@ class GpuBackend:
         n = gamma.size
         return self._go("snn_msbl1_party_finish", _c(gamma, np.int64), _c(delta, np.int64), _c(theta, np.int64), n,
                         ("out", np.int64, n))
+
+
+class ResidentBackend(GpuBackend):
+    """GpuBackend whose arrays stay on the device: inputs and outputs are DeviceArrays borrowed from torch's
+    caching allocator, nothing is copied to the host and nothing synchronises.  Used to time whole protocols
+    (bench.py); `up` / `down` move test data in and out."""
+    name = "gpu-resident"
+
+    def __init__(self, ctx, torch, dev):
+        super().__init__(ctx)
+        self.torch, self.dev = torch, dev
+        self._tdt = {np.dtype(np.int64): torch.int64, np.dtype(np.uint64): torch.int64, np.dtype(np.int8): torch.int8,
+                     np.dtype(np.uint16): torch.int16}
+
+    def empty(self, dtype, n):
+        t = self.torch.empty(max(int(n), 1), dtype=self._tdt[np.dtype(dtype)], device=self.dev)
+        return self.ctx.wrap(t, dtype).view(0, int(n))
+
+    def up(self, a):
+        a = np.ascontiguousarray(a)
+        t = self.torch.from_numpy(a.view(np.int16) if a.dtype == np.uint16 else a).to(self.dev)
+        return self.ctx.wrap(t, a.dtype)
+
+    def down(self, d):
+        self.ctx.sync()
+        return d.to_host()
+
+    def _go(self, name, *args):
+        dev, outs = [], []
+        for a in args:
+            if isinstance(a, tuple) and len(a) == 3 and a[0] == "out":
+                d = self.empty(a[1], a[2])
+                outs.append(d)
+                dev.append(d)
+            else:
+                dev.append(a)
+        self._run(name, *dev)
+        return outs[0] if len(outs) == 1 else outs
+
+    def _run(self, name, *dev):
+        if self.events is None:
+            self.ctx.call(name, *dev)
+            return
+        # per-segment device time (the context runs on torch's current stream)
+        e0, e1 = self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True)
+        e0.record()
+        self.ctx.call(name, *dev)
+        e1.record()
+        self.events.append((name, e0, e1))
+
+    events = None
+
+    def segment_ms(self):
+        """Device milliseconds per segment name, summed over the calls recorded since `events = []`."""
+        self.torch.cuda.synchronize()
+        out = {}
+        for name, e0, e1 in self.events:
+            out[name] = out.get(name, 0.0) + e0.elapsed_time(e1)
+        return out
+
+    def ring_gemm(self, *a, **k):
+        raise NotImplementedError
+
+    class _Msb:
+        def __init__(self, be, G0, G1, P0, P1):
+            self.be, self.n, self.P0, self.P1 = be, G0.size, P0, P1
+            self.state = be.empty(np.uint64, 4 * self.n)
+            be._run("aby3_msb_begin", G0, G1, P0, P1, self.n, self.state)
+
+        def round_pre(self, temp):
+            msg = self.be.empty(np.int8, self.n * 2 * temp)
+            self.be._run("aby3_msb_round_pre", self.state, self.n, temp, msg)
+            return msg
+
+        def round_post(self, temp, msg_in):
+            self.be._run("aby3_msb_round_post", self.state, self.n, temp, msg_in)
+
+        def final(self):
+            Z0, Z1 = self.be.empty(np.int8, self.n), self.be.empty(np.int8, self.n)
+            self.be._run("aby3_msb_final", self.state, self.P0, self.P1, self.n, Z0, Z1)
+            return Z0, Z1
+
+    def aby3_msb_begin(self, G0, G1, P0, P1):
+        return ResidentBackend._Msb(self, G0, G1, P0, P1)

@@ -130,7 +130,7 @@ def test_aby3_matmul_row_blocks_equal_whole(gpu, orc):
     assert np.array_equal(np.concatenate(parts), whole)
 
 
-@pytest.mark.parametrize("n", [1, 4, 63, 1000, 4097])
+@pytest.mark.parametrize("n", [1, 4, 63, 1000, 4097, (1 << 20) + 4099])  # the last: every kernel grid-strides
 def test_aby3_relu_chain_parity(gpu, orc, n):
     """share -> add_prepare -> msb -> bit_inject: every message and every share equals the oracle's."""
     X = prg_pops(21, 0, n)

@@ -116,7 +116,7 @@ def test_snn_matmul_protocol_parity(gpu, orc, r, l, c, layout):
     assert np.array_equal(tr(pr.snn_reveal(wg, Zg), r, c), orc.ring_gemm(X, Y, r, l, c))
 
 
-@pytest.mark.parametrize("n", [1, 10, 1000, 2000])
+@pytest.mark.parametrize("n", [1, 10, 1000, 2000, (1 << 20) + 77])  # the last: every kernel grid-strides
 def test_snn_msb_parity(gpu, orc, n):
     """n = 2000 is the reference benchmark's size, which the reference itself cannot run (buffer overrun)."""
     a = trunc_div2(prg_pops(22, 67 * 1000, n))
