@@ -39,6 +39,16 @@ def pair_seed(a, b):
     return {frozenset((0, 1)): KEY01, frozenset((1, 2)): KEY12, frozenset((0, 2)): KEY20}[frozenset((a, b))]
 
 
+def measured_traffic(n, world):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE doubled
+    as gfx950 requires, + WRITE_SIZE); they were taken on the default single-GPU workload only."""
+    path = os.path.join(ROOT, "profiles", "r1_pmc_summary.json")
+    if n != 4096 or world != 1 or not os.path.exists(path):
+        return None
+    d = json.load(open(path))["limb_gemm_kernel"]["derived"]
+    return d["hbm_read_bytes_per_launch"] + d["hbm_write_bytes_per_launch"]
+
+
 def prof_read(ctx, name):
     ms, cnt = ctypes.c_double(), ctypes.c_uint64()
     ctx._call("mpcx_profile_read", name.encode(), ctypes.byref(ms), ctypes.byref(cnt))
@@ -108,6 +118,11 @@ class Aby3MatmulJob:
             i, k = int(rng.integers(self.rows)), int(rng.integers(self.c))
             want = sum(int(a) * int(b) for a, b in zip(X[i], Y[:, k])) % (1 << 64)
             assert int(Z[i, k]) == want, f"Z[{i},{k}] wrong"
+        # every entry at once: Z v == X (Y v) over Z_2^64 for random vectors v (numpy uint64 arithmetic wraps)
+        with np.errstate(over="ignore"):
+            for _ in range(4):
+                v = rng.integers(0, 1 << 64, self.c, dtype=np.uint64) | np.uint64(1)
+                assert np.array_equal(Z @ v, X @ (Y @ v)), "Z v != X (Y v)"
 
 
 def cpu_baseline(n=1024):
@@ -331,7 +346,8 @@ def main():
                                    "inputs from PRgenerator(20,0)",
                        "rows_per_gpu": job.rows, "parallelism": f"row-block x{world}" if world > 1 else "single GPU"},
             "roofline": {"bound": "mfma", "kernel": "limb_gemm_kernel", "achieved": achieved, "peak": INT8_PEAK_TOPS,
-                         "unit": "TFLOP/s", "frac": achieved / INT8_PEAK_TOPS, "traffic": None,
+                         "unit": "TFLOP/s", "frac": achieved / INT8_PEAK_TOPS, "traffic": measured_traffic(args.n, world),
+                         "traffic_unit": "bytes per launch (profiles/r1_pmc_summary.json)",
                          "avg_launch_ms": avg_s * 1e3, "launches": gemm_cnt,
                          "note": "int8 TOP/s: 36 limb pairs x 2 x rows x c x 2l per launch"},
             "kernel_ms_per_step": breakdown,
