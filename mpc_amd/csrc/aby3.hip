@@ -1,6 +1,7 @@
 // Per-party local segments of ABY3Engine (mpc_engine/ABY3Engine.cpp) as HIP kernels.
 // All kernels are streaming, HBM-bound passes over 64-bit share words; the carry tree of msb() is
-// kept as packed 64-bit words and only the wire messages are expanded to one byte per bit.
+// kept as packed words that halve in width every round, and only the wire messages are expanded to
+// one byte per bit.
 #include "mpcx_internal.h"
 
 namespace {
@@ -17,52 +18,79 @@ template <class F> int ew_launch(mpcx_ctx *ctx, u64 n, F f) {
     return 0;
 }
 
-// mask of the carry-tree positions that are still live when pairs are S bits apart: bits at multiples of 2S
-template <u32 S> __device__ constexpr u64 even_mask() {
-    return S == 1 ? 0x5555555555555555ull
-         : S == 2 ? 0x1111111111111111ull
-         : S == 4 ? 0x0101010101010101ull
-         : S == 8 ? 0x0001000100010001ull
-         : S == 16 ? 0x0000000100000001ull
-                   : 1ull;
+// ---- msb() carry tree (ABY3Engine.cpp:361-467) on packed words ----------------------------------------------
+// The reference keeps one byte per bit and halves the vectors every round.  Here the 2*TEMP bits an element
+// still has before the round with TEMP pairs are kept dense in the low bits of one word per share array
+// (G0, G1, P0, P1), and every round writes words of half the width: u64 -> u32 -> u16 -> u8 (4, 2, 1 bits).
+// `state` is 48*n bytes; the arrays of each level live at fixed offsets so that a round never writes what
+// another lane of the same launch still reads:
+//   level (pairs) : 32      16       8       4       2       1       0 (result)
+//   byte offset   : 0       32n      0       8n      12n     16n     20n
+//   word bytes    : 8       4        2       1       1       1       1
+template <u32 TEMP> struct MsbLevel {
+    static constexpr u32 BYTES = TEMP == 32 ? 8 : TEMP == 16 ? 4 : TEMP == 8 ? 2 : 1;
+    static constexpr u32 BASE = TEMP == 32 ? 0 : TEMP == 16 ? 32 : TEMP == 8 ? 0 : TEMP == 4 ? 8 : TEMP == 2 ? 12 : TEMP == 1 ? 16 : 20;
+    static constexpr u32 G = TEMP >= 4 ? TEMP / 4 : 1; // lanes per element in this level's round
+    static constexpr u32 NP = TEMP >= 4 ? 4 : TEMP;    // pairs per lane = 2*NP wire bytes
+    static constexpr u64 EVEN = TEMP == 32 ? 0x5555555555555555ull : (0x5555555555555555ull & ((1ull << (2 * TEMP)) - 1));
+    __device__ static u64 load(const u8 *st, u64 n, u32 arr, u64 k) {
+        const u8 *p = st + ((u64)BASE + (u64)arr * BYTES) * n + k * BYTES;
+        if (BYTES == 8) return *(const u64 *)p;
+        if (BYTES == 4) return *(const u32 *)p;
+        if (BYTES == 2) return *(const u16 *)p;
+        return *p;
+    }
+    __device__ static void store(u8 *st, u64 n, u32 arr, u64 k, u64 v) {
+        u8 *p = st + ((u64)BASE + (u64)arr * BYTES) * n + k * BYTES;
+        if (BYTES == 8)
+            *(u64 *)p = v;
+        else if (BYTES == 4)
+            *(u32 *)p = (u32)v;
+        else if (BYTES == 2)
+            *(u16 *)p = (u16)v;
+        else
+            *p = (u8)v;
+    }
+};
+// bits 0,2,4,.. of x moved to bits 0,1,2,..
+__device__ inline u64 compress_even(u64 x) {
+    x &= 0x5555555555555555ull;
+    x = (x | (x >> 1)) & 0x3333333333333333ull;
+    x = (x | (x >> 2)) & 0x0F0F0F0F0F0F0F0Full;
+    x = (x | (x >> 4)) & 0x00FF00FF00FF00FFull;
+    x = (x | (x >> 8)) & 0x0000FFFF0000FFFFull;
+    x = (x | (x >> 16)) & 0x00000000FFFFFFFFull;
+    return x;
 }
-// this round's product share of the element (ABY3Engine.cpp:397-414 + :253-256) on packed words:
-// even result bits pair (P[2m+1], G[2m]), odd result bits pair (P[2m+1], P[2m]); bit m sits at 2*m*S.
-template <u32 S> __device__ inline void msb_products(u64 g0, u64 g1, u64 p0, u64 p1, u64 &re, u64 &ro) {
-    constexpr u64 E = even_mask<S>();
-    const u64 po0 = (p0 >> S) & E, po1 = (p1 >> S) & E;
+// this round's product share (ABY3Engine.cpp:397-414 + :253-256): bit 2m of `re` pairs (P[2m+1], G[2m]), bit 2m
+// of `ro` pairs (P[2m+1], P[2m]); shared AND = (x0&y0)^(x1&y0)^(x0&y1), no re-randomisation (:255)
+template <u32 TEMP> __device__ inline void msb_products(u64 g0, u64 g1, u64 p0, u64 p1, u64 &re, u64 &ro) {
+    constexpr u64 E = MsbLevel<TEMP>::EVEN;
+    const u64 po0 = (p0 >> 1) & E, po1 = (p1 >> 1) & E;
     const u64 ge0 = g0 & E, ge1 = g1 & E, pe0 = p0 & E, pe1 = p1 & E;
     re = (po0 & ge0) ^ (po1 & ge0) ^ (po0 & ge1);
     ro = (po0 & pe0) ^ (po1 & pe0) ^ (po0 & pe1);
 }
-
-// Work split of one round with `TEMP` pairs per element (2*TEMP wire bytes per element): an element is
-// handled by G adjacent lanes, each owning NP pairs = 2*NP consecutive wire bytes.
-template <u32 TEMP> struct MsbGeom {
-    static constexpr u32 S = 32 / TEMP;              // distance of the two bits of a pair in the packed word
-    static constexpr u32 G = TEMP >= 4 ? TEMP / 4 : 1; // lanes per element
-    static constexpr u32 NP = TEMP / G;               // pairs per lane: 4, 2 or 1
-};
-// wire bytes of pairs m0 .. m0+NP-1: byte 2j = even bit, byte 2j+1 = odd bit
-template <u32 TEMP> __device__ inline u64 msb_pack(u64 re, u64 ro, u32 m0) {
-    using Ge = MsbGeom<TEMP>;
+// wire bytes of the lane's NP pairs m0 .. m0+NP-1: byte 2j = even result bit, byte 2j+1 = odd result bit
+template <u32 NP> __device__ inline u64 msb_pack(u64 re, u64 ro, u32 m0) {
+    const u32 rb = (u32)(re >> (2 * m0)), ob = (u32)(ro >> (2 * m0));
     u64 w = 0;
 #pragma unroll
-    for (u32 j = 0; j < Ge::NP; j++) {
-        const u32 pos = 2 * (m0 + j) * Ge::S;
-        w |= ((re >> pos) & 1ull) << (16 * j);
-        w |= ((ro >> pos) & 1ull) << (16 * j + 8);
+    for (u32 j = 0; j < NP; j++) {
+        w |= (u64)((rb >> (2 * j)) & 1u) << (16 * j);
+        w |= (u64)((ob >> (2 * j)) & 1u) << (16 * j + 8);
     }
     return w;
 }
-template <u32 TEMP> __device__ inline void msb_unpack(u64 w, u32 m0, u64 &re, u64 &ro) {
-    using Ge = MsbGeom<TEMP>;
+template <u32 NP> __device__ inline void msb_unpack(u64 w, u32 m0, u64 &re, u64 &ro) {
+    u64 rb = 0, ob = 0;
 #pragma unroll
-    for (u32 j = 0; j < Ge::NP; j++) {
-        const u32 pos = 2 * (m0 + j) * Ge::S;
-        re |= ((w >> (16 * j)) & 1ull) << pos;
-        ro |= ((w >> (16 * j + 8)) & 1ull) << pos;
+    for (u32 j = 0; j < NP; j++) {
+        rb |= ((w >> (16 * j)) & 1ull) << (2 * j);
+        ob |= ((w >> (16 * j + 8)) & 1ull) << (2 * j);
     }
+    re = rb << (2 * m0);
+    ro = ob << (2 * m0);
 }
 template <u32 NP> __device__ inline void msb_store_piece(u8 *msg, u64 c, u64 w) {
     if (NP == 4)
@@ -78,49 +106,50 @@ template <u32 NP> __device__ inline u64 msb_load_piece(const u8 *msg, u64 c) {
     return (u64) * (const u16 *)(msg + 2 * c);
 }
 
-// before the round: every lane computes the element's product share and writes its piece of the message;
-// the element's first lane then advances share 0 of the state (:424-425 with i = 0): G' = res_even ^ G_odd,
-// P' = res_odd.  The G lanes of an element sit in one wavefront and all of them load the state before the
-// first lane stores it.
-template <u32 TEMP> __global__ __launch_bounds__(256) void msb_round_pre_kernel(u64 *st, u64 n, u8 *__restrict__ msg) {
-    using Ge = MsbGeom<TEMP>;
-    const u64 pieces = n * Ge::G;
+// before the round: every lane computes the element's product share and writes its piece of the message; the
+// element's first lane then writes share 0 of the next level (:424-425 with i = 0): G' = res_even ^ G_odd,
+// P' = res_odd, compacted.
+template <u32 TEMP> __global__ __launch_bounds__(256) void msb_round_pre_kernel(u8 *st, u64 n, u8 *__restrict__ msg) {
+    using In = MsbLevel<TEMP>;
+    using Out = MsbLevel<TEMP / 2>;
+    const u64 pieces = n * In::G;
     for (u64 c = (u64)blockIdx.x * 256 + threadIdx.x; c < pieces; c += (u64)gridDim.x * 256) {
-        const u64 k = c / Ge::G;
-        const u32 q = (u32)(c % Ge::G);
-        const u64 g0 = st[k], g1 = st[n + k], p0 = st[2 * n + k], p1 = st[3 * n + k];
+        const u64 k = c / In::G;
+        const u32 q = (u32)(c % In::G);
+        const u64 g0 = In::load(st, n, 0, k), g1 = In::load(st, n, 1, k), p0 = In::load(st, n, 2, k), p1 = In::load(st, n, 3, k);
         u64 re, ro;
-        msb_products<Ge::S>(g0, g1, p0, p1, re, ro);
-        msb_store_piece<Ge::NP>(msg, c, msb_pack<TEMP>(re, ro, Ge::NP * q));
+        msb_products<TEMP>(g0, g1, p0, p1, re, ro);
+        msb_store_piece<In::NP>(msg, c, msb_pack<In::NP>(re, ro, In::NP * q));
         if (q == 0) {
-            st[k] = re ^ ((g0 >> Ge::S) & even_mask<Ge::S>());
-            st[2 * n + k] = ro;
+            Out::store(st, n, 0, k, compress_even(re ^ ((g0 >> 1) & In::EVEN)));
+            Out::store(st, n, 2, k, compress_even(ro));
         }
     }
 }
 // after the round (:416-428 with i = 1): msg = result[1] from the next party; the G lanes of an element OR
-// their pieces together and the first lane advances share 1 of the state.
-template <u32 TEMP> __global__ __launch_bounds__(256) void msb_round_post_kernel(u64 *st, u64 n, const u8 *__restrict__ msg) {
-    using Ge = MsbGeom<TEMP>;
-    const u64 pieces = n * Ge::G;
+// their pieces together and the first lane writes share 1 of the next level.
+template <u32 TEMP> __global__ __launch_bounds__(256) void msb_round_post_kernel(u8 *st, u64 n, const u8 *__restrict__ msg) {
+    using In = MsbLevel<TEMP>;
+    using Out = MsbLevel<TEMP / 2>;
+    const u64 pieces = n * In::G;
     // every lane of a group must reach the shuffles: iterate on a wave-uniform trip count
     const u64 stride = (u64)gridDim.x * 256;
     for (u64 base = (u64)blockIdx.x * 256; base < pieces; base += stride) {
         const u64 c = base + threadIdx.x;
         const bool live = c < pieces; // pieces is a multiple of G, so a group is all-live or all-dead
-        const u64 k = live ? c / Ge::G : 0;
-        const u32 q = (u32)(c % Ge::G);
+        const u64 k = live ? c / In::G : 0;
+        const u32 q = (u32)(c % In::G);
         u64 re = 0, ro = 0;
-        if (live) msb_unpack<TEMP>(msb_load_piece<Ge::NP>(msg, c), Ge::NP * q, re, ro);
+        if (live) msb_unpack<In::NP>(msb_load_piece<In::NP>(msg, c), In::NP * q, re, ro);
 #pragma unroll
-        for (u32 d = 1; d < Ge::G; d <<= 1) { // groups are aligned runs of G lanes (G divides 64)
-            re |= __shfl_xor(re, (int)d, (int)Ge::G);
-            ro |= __shfl_xor(ro, (int)d, (int)Ge::G);
+        for (u32 d = 1; d < In::G; d <<= 1) { // groups are aligned runs of G lanes (G divides 64)
+            re |= __shfl_xor(re, (int)d, (int)In::G);
+            ro |= __shfl_xor(ro, (int)d, (int)In::G);
         }
         if (live && q == 0) {
-            const u64 g1 = st[n + k];
-            st[n + k] = re ^ ((g1 >> Ge::S) & even_mask<Ge::S>());
-            st[3 * n + k] = ro;
+            const u64 g1 = In::load(st, n, 1, k);
+            Out::store(st, n, 1, k, compress_even(re ^ ((g1 >> 1) & In::EVEN)));
+            Out::store(st, n, 3, k, compress_even(ro));
         }
     }
 }
@@ -285,7 +314,7 @@ int mpcx_aby3_msb_begin(mpcx_ctx *ctx, const int64_t *G0, const int64_t *G1, con
                         uint64_t n, uint64_t *state) {
     MPCX_REQUIRE((G0 && G1 && P0 && P1 && state) || n == 0, "mpcx_aby3_msb_begin: NULL pointer");
     const u64 top = 1ull << 63;
-    return ew_launch(ctx, n, [=] __device__(u64 i) {
+    return ew_launch(ctx, n, [=] __device__(u64 i) { // level 32: four arrays of n 64-bit words
         state[i] = (u64)G0[i] & ~top; // ABY3Engine.cpp:386
         state[n + i] = (u64)G1[i] & ~top;
         state[2 * n + i] = (u64)P0[i] | top; // :387
@@ -301,8 +330,8 @@ int mpcx_aby3_msb_round_pre(mpcx_ctx *ctx, uint64_t *state, uint64_t n, uint64_t
     ProfScope ps(ctx, PROF_MSB);
 #define MSB_PRE(T)                                                                                                     \
     case T:                                                                                                            \
-        hipLaunchKernelGGL(msb_round_pre_kernel<T>, dim3(grid_for(n * MsbGeom<T>::G)), dim3(256), 0, ctx->stream, state, \
-                           n, (u8 *)msg_out);                                                                          \
+        hipLaunchKernelGGL(msb_round_pre_kernel<T>, dim3(grid_for(n * MsbLevel<T>::G)), dim3(256), 0, ctx->stream,      \
+                           (u8 *)state, n, (u8 *)msg_out);                                                             \
         break;
     switch (temp) {
         MSB_PRE(32) MSB_PRE(16) MSB_PRE(8) MSB_PRE(4) MSB_PRE(2) MSB_PRE(1)
@@ -320,8 +349,8 @@ int mpcx_aby3_msb_round_post(mpcx_ctx *ctx, uint64_t *state, uint64_t n, uint64_
     ProfScope ps(ctx, PROF_MSB);
 #define MSB_POST(T)                                                                                                    \
     case T:                                                                                                            \
-        hipLaunchKernelGGL(msb_round_post_kernel<T>, dim3(grid_for(n * MsbGeom<T>::G)), dim3(256), 0, ctx->stream,     \
-                           state, n, (const u8 *)msg_in);                                                              \
+        hipLaunchKernelGGL(msb_round_post_kernel<T>, dim3(grid_for(n * MsbLevel<T>::G)), dim3(256), 0, ctx->stream,     \
+                           (u8 *)state, n, (const u8 *)msg_in);                                                        \
         break;
     switch (temp) {
         MSB_POST(32) MSB_POST(16) MSB_POST(8) MSB_POST(4) MSB_POST(2) MSB_POST(1)
@@ -333,9 +362,10 @@ int mpcx_aby3_msb_round_post(mpcx_ctx *ctx, uint64_t *state, uint64_t n, uint64_
 int mpcx_aby3_msb_final(mpcx_ctx *ctx, const uint64_t *state, const int64_t *P0_in, const int64_t *P1_in, uint64_t n,
                         int8_t *Z0, int8_t *Z1) {
     MPCX_REQUIRE((state && P0_in && P1_in && Z0 && Z1) || n == 0, "mpcx_aby3_msb_final: NULL pointer");
-    return ew_launch(ctx, n, [=] __device__(u64 i) {
-        Z0[i] = (i8)((state[i] & 1) ^ ((u64)P0_in[i] >> 63));
-        Z1[i] = (i8)((state[n + i] & 1) ^ ((u64)P1_in[i] >> 63));
+    const u8 *st = (const u8 *)state;
+    return ew_launch(ctx, n, [=] __device__(u64 i) { // level 0: one byte per element and array
+        Z0[i] = (i8)((MsbLevel<0>::load(st, n, 0, i) & 1) ^ ((u64)P0_in[i] >> 63));
+        Z1[i] = (i8)((MsbLevel<0>::load(st, n, 1, i) & 1) ^ ((u64)P1_in[i] >> 63));
     });
 }
 

@@ -237,7 +237,7 @@ void ABY3Engine::msb(const array<VecI64, 2> &Gj, const array<VecI64, 2> &Pj, arr
     const size_t n = Gj[0].size();
     assert(n == (size_t)Gj[1].size() && n == (size_t)Pj[0].size() && n == (size_t)Pj[1].size());
     Dev<int64_t> p0(gpu, Pj[0].data(), n), p1(gpu, Pj[1].data(), n);
-    Dev<uint64_t> state(gpu, 4 * n);
+    Dev<uint64_t> state(gpu, 6 * n);
     {
         Dev<int64_t> g0(gpu, Gj[0].data(), n), g1(gpu, Gj[1].data(), n);
         GPU_OK(gpu, mpcx_aby3_msb_begin(gpu, g0, g1, p0, p1, n, state));

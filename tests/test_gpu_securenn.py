@@ -177,6 +177,45 @@ def test_snn_relu_layer(gpu, orc):
     assert np.array_equal(got, np.maximum(a_plain, 0))
 
 
+def test_snn_mlp_config4(gpu, orc):
+    """The 784-128-128-10 MLP at batch 128: input and W1..W3 are PRgenerator(24,0).pop_int64() >> 48 in that order;
+    per layer matrix_mul -> local >> 16 -> msb -> vector_mul(a, msb) -> a - that, no ReLU after the last layer
+    (the composition of benchmark/benchmark1.cpp:104-136).  The Beaver triples of the first layer alone need
+    417 792 buffer words, far beyond BUFF_NUM: every message and share must still equal the oracle's."""
+    dims = [(128, 784, 128), (128, 128, 128), (128, 128, 10)]
+    words = prg_pops(24, 0, 128 * 784 + sum(l * c for _, l, c in dims)) >> 48
+    X, off = words[: 128 * 784].copy(), 128 * 784
+    Ws = []
+    for _, l, c in dims:
+        Ws.append(words[off: off + l * c].copy())
+        off += l * c
+    outs = []
+    for be in (gpu, orc):
+        w = pr.World(be)
+        act = pr.snn_share(w, X, X.size)[:2]
+        for li, (r, l, c) in enumerate(dims):
+            Wsh = pr.snn_share(w, Ws[li], l * c)[:2]
+            Z = pr.snn_matmul(w, act, Wsh, r, l, c)
+            a = [be.ring_sar(Z[0], 16), be.ring_sar(Z[1], 16)]
+            if li < 2:
+                m = pr.snn_msb(w, a)
+                am = pr.snn_vecmul(w, a, m)
+                a = [be.ring_sub(a[j], am[j]) for j in range(2)]
+            act = a
+        outs.append((w, act))
+    same_logs(outs[0][0], outs[1][0])
+    for j in range(2):
+        assert np.array_equal(outs[0][1][j], outs[1][1][j])
+    # plaintext network with the same fixed-point rule; local truncation of shares is off by at most one per layer
+    h = X.reshape(128, 784)
+    for li, (r, l, c) in enumerate(dims):
+        h = (h @ Ws[li].reshape(l, c)) >> 16
+        if li < 2:
+            h = np.maximum(h, 0)
+    got = pr.snn_reveal(outs[0][0], outs[0][1]).reshape(128, 10)
+    assert np.abs(got - h).max() <= 64
+
+
 def test_snn_small_segments_parity(gpu, orc):
     n = 333
     rng = np.random.default_rng(8)
