@@ -42,8 +42,12 @@ const char *mpcx_last_error(mpcx_ctx *ctx); /* ctx may be NULL: error of a faile
 int mpcx_set_stream(mpcx_ctx *ctx, void *hip_stream);
 void *mpcx_get_stream(mpcx_ctx *ctx);
 int mpcx_sync(mpcx_ctx *ctx);
+/* device memory.  Freed blocks are recycled by later mpcx_malloc calls of the same context (all work of a
+ * context is ordered on its stream, so mpcx_free never waits); at most max_idle_bytes (default 8 GiB) are
+ * kept idle, the rest goes back to the driver. */
 int mpcx_malloc(mpcx_ctx *ctx, uint64_t bytes, void **out);
 int mpcx_free(mpcx_ctx *ctx, void *p);
+int mpcx_set_pool_limit(mpcx_ctx *ctx, uint64_t max_idle_bytes);
 int mpcx_h2d(mpcx_ctx *ctx, void *dst, const void *src, uint64_t bytes);
 int mpcx_d2h(mpcx_ctx *ctx, void *dst, const void *src, uint64_t bytes);
 int mpcx_d2d(mpcx_ctx *ctx, void *dst, const void *src, uint64_t bytes);

@@ -72,6 +72,8 @@ int mpcx_shutdown(mpcx_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->ws) (void)hipFree(ctx->ws);
     prg_rand_cache_clear(ctx);
+    for (auto &b : ctx->pool_free) (void)hipFree(b.second);
+    for (auto &b : ctx->pool_live) (void)hipFree(b.first);
     for (auto &v : ctx->prof_ev)
         for (auto &p : v) {
             (void)hipEventDestroy(p.first);
@@ -85,10 +87,9 @@ int mpcx_shutdown(mpcx_ctx *ctx) {
 const char *mpcx_last_error(mpcx_ctx *ctx) { return ctx ? ctx->err.c_str() : g_init_err.c_str(); }
 
 int mpcx_set_stream(mpcx_ctx *ctx, void *hip_stream) {
-    if (ctx->own_stream && ctx->stream) {
-        MPCX_HIP(hipStreamSynchronize(ctx->stream));
-        MPCX_HIP(hipStreamDestroy(ctx->stream));
-    }
+    // work queued on the old stream may still use the workspace, cached slices and recycled blocks
+    MPCX_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->own_stream && ctx->stream) MPCX_HIP(hipStreamDestroy(ctx->stream));
     ctx->stream = (hipStream_t)hip_stream;
     ctx->own_stream = false;
     return 0;
@@ -99,15 +100,54 @@ int mpcx_sync(mpcx_ctx *ctx) {
     MPCX_HIP(hipStreamSynchronize(ctx->stream));
     return 0;
 }
+static int pool_drain(mpcx_ctx *ctx) {
+    if (ctx->pool_free.empty()) return 0;
+    MPCX_HIP(hipStreamSynchronize(ctx->stream));
+    for (auto &b : ctx->pool_free) MPCX_HIP(hipFree(b.second));
+    ctx->pool_free.clear();
+    ctx->pool_idle_bytes = 0;
+    return 0;
+}
 int mpcx_malloc(mpcx_ctx *ctx, uint64_t bytes, void **out) {
+    MPCX_REQUIRE(out, "mpcx_malloc: out is NULL");
+    const u64 want = ((bytes ? bytes : 8) + 255) & ~255ull;
+    // smallest idle block that fits and wastes at most a quarter
+    auto it = ctx->pool_free.lower_bound(want);
+    if (it != ctx->pool_free.end() && it->first <= want + want / 4) {
+        *out = it->second;
+        ctx->pool_live[it->second] = it->first;
+        ctx->pool_idle_bytes -= it->first;
+        ctx->pool_free.erase(it);
+        return 0;
+    }
     MPCX_HIP(hipSetDevice(ctx->device));
-    MPCX_HIP(hipMalloc(out, bytes ? bytes : 8));
+    hipError_t e = hipMalloc(out, want);
+    if (e != hipSuccess) { // give the idle blocks back to the driver and try once more
+        (void)hipGetLastError();
+        MPCX_TRY(pool_drain(ctx));
+        MPCX_HIP(hipMalloc(out, want));
+    }
+    ctx->pool_live[*out] = want;
     return 0;
 }
 int mpcx_free(mpcx_ctx *ctx, void *p) {
     if (!p) return 0;
-    MPCX_HIP(hipStreamSynchronize(ctx->stream));
-    MPCX_HIP(hipFree(p));
+    auto it = ctx->pool_live.find(p);
+    MPCX_REQUIRE(it != ctx->pool_live.end(), "mpcx_free: %p was not allocated by mpcx_malloc on this context", p);
+    const u64 size = it->second;
+    ctx->pool_live.erase(it);
+    if (ctx->pool_idle_bytes + size > ctx->pool_cap) {
+        MPCX_HIP(hipStreamSynchronize(ctx->stream));
+        MPCX_HIP(hipFree(p));
+        return 0;
+    }
+    ctx->pool_free.emplace(size, p);
+    ctx->pool_idle_bytes += size;
+    return 0;
+}
+int mpcx_set_pool_limit(mpcx_ctx *ctx, uint64_t max_idle_bytes) {
+    ctx->pool_cap = max_idle_bytes;
+    if (ctx->pool_idle_bytes > max_idle_bytes) return pool_drain(ctx);
     return 0;
 }
 int mpcx_h2d(mpcx_ctx *ctx, void *dst, const void *src, uint64_t bytes) {

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
+#include <map>
 #include <string>
 #include <utility>
 #include <vector>
@@ -48,6 +49,11 @@ struct mpcx_ctx {
     };
     std::vector<RandEntry> rand_cache;
     u64 rand_bytes = 0, rand_cap = 4ull << 30, rand_tick = 0;
+    // mpcx_malloc / mpcx_free recycle device blocks: every use of a block is ordered on the context's stream,
+    // so a freed block can be handed out again without waiting for the kernels that still read it.
+    std::multimap<u64, void *> pool_free; // idle blocks by size
+    std::map<void *, u64> pool_live;      // blocks handed out -> size
+    u64 pool_idle_bytes = 0, pool_cap = 8ull << 30;
 };
 
 int mpcx_fail(mpcx_ctx *ctx, const char *fmt, ...);

@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void split_limbs_kernel(const u64 *__restrict_
 template <int ABL>
 __global__ __launch_bounds__(512) void limb_gemm_kernel(const i8 *__restrict__ Apl, const i8 *__restrict__ Bpl,
                                                         i32 *__restrict__ Cpl, u32 Mp, u32 Np, u32 nkb, u32 tiles_m,
-                                                        u32 tiles_n) {
+                                                        u32 tiles_n, u32 GM) {
     __shared__ __attribute__((aligned(1024))) i8 lds[2 * STAGE_BYTES]; // 96 KiB: two staging buffers
     const u32 tid = threadIdx.x, lane = tid & 63;
     const u32 wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -104,7 +104,6 @@ __global__ __launch_bounds__(512) void limb_gemm_kernel(const i8 *__restrict__ A
     const u32 bid = blockIdx.x;
     const u32 qq = nwg / 8, rem = nwg % 8, xcd = bid % 8;
     const u32 swz = (xcd < rem ? xcd * (qq + 1) : rem * (qq + 1) + (xcd - rem) * qq) + bid / 8;
-    const u32 GM = 4;
     const u32 per_group = GM * tiles_n;
     const u32 group = swz / per_group, in_group = swz % per_group;
     const u32 first_m = group * GM;
@@ -222,6 +221,47 @@ __global__ __launch_bounds__(512) void limb_gemm_kernel(const i8 *__restrict__ A
     }
 }
 
+
+// Development probe (MPCX_GEMM_ABLATE=3, results are garbage): the MFMA stream of limb_gemm_kernel re-expressed
+// with v_mfma_i32_16x16x64_i8 (four per 32x32 tile and 64 bytes of K), fragments read from LDS, nothing staged.
+// Only its run time and the clock the chip holds are of interest.
+__global__ __launch_bounds__(512) void limb_gemm_shape_probe(i32 *__restrict__ Cpl, u32 Mp, u32 Np, u32 nkb) {
+    __shared__ __attribute__((aligned(1024))) i8 lds[2 * STAGE_BYTES];
+    const u32 tid = threadIdx.x, lane = tid & 63;
+    const u32 wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const u32 off = ((wid * 64 + lane) * 16) & (STAGE_BYTES - 1);
+    v4i acc[8][4];
+#pragma unroll
+    for (int s = 0; s < 8; s++)
+#pragma unroll
+        for (int t = 0; t < 4; t++) acc[s][t] = v4i{0, 0, 0, 0};
+    for (u32 kb = 0; kb < nkb; kb += 2) {
+        v4i a[8][2], b[8][2];
+#pragma unroll
+        for (u32 i = 0; i < 8; i++)
+#pragma unroll
+            for (u32 h = 0; h < 2; h++) {
+                a[i][h] = *(const v4i *)(lds + ((off + i * 4096 + h * 2048) & (2 * STAGE_BYTES - 16)));
+                b[i][h] = *(const v4i *)(lds + ((off + 40960 + i * 2048 + h * 1024) & (2 * STAGE_BYTES - 16)));
+            }
+#pragma unroll
+        for (u32 i = 0; i < 8; i++)
+#pragma unroll
+            for (u32 j = 0; j + i < 8; j++)
+#pragma unroll
+                for (u32 t = 0; t < 4; t++)
+                    acc[i + j][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[i][t >> 1], b[j][t & 1], acc[i + j][t], 0, 0, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    i32 *out = Cpl + ((u64)blockIdx.x * 512 + tid) * 4 % ((u64)Mp * Np);
+    v4i sum = v4i{0, 0, 0, 0};
+#pragma unroll
+    for (int s = 0; s < 8; s++)
+#pragma unroll
+        for (int t = 0; t < 4; t++) sum += acc[s][t];
+    *(v4i *)out = sum;
+}
+
 // ---------------------------------------------------------------- combine
 // Z[m][n] (+)= sum_s (int64)Cpl[s][m][n] << 8s  (+ add[idx] - sub[idx]), idx = m*N + n (row-major)
 __global__ __launch_bounds__(256) void combine_kernel(const i32 *__restrict__ Cpl, u64 Mp, u64 Np, u64 M, u64 N,
@@ -300,6 +340,7 @@ int ring_gemm_parts(mpcx_ctx *ctx, const GemmPart *parts, int nparts, u64 r, u64
     const u64 soA = layA ? 1 : l, skA = layA ? r : 1; // A(o=row, k)
     const u64 soB = layB ? l : 1, skB = layB ? 1 : c; // B(o=col, k)
     static const int abl = getenv("MPCX_GEMM_ABLATE") ? atoi(getenv("MPCX_GEMM_ABLATE")) : 0;
+    static const u32 gm = getenv("MPCX_GEMM_GM") ? (u32)atoi(getenv("MPCX_GEMM_GM")) : 4;
     int first = 1;
     for (u64 kb = 0; kb < l; kb += lc) {
         const u64 klen = (l - kb < lc) ? l - kb : lc;
@@ -316,15 +357,17 @@ int ring_gemm_parts(mpcx_ctx *ctx, const GemmPart *parts, int nparts, u64 r, u64
         {
             ProfScope ps(ctx, PROF_GEMM);
             const dim3 grid(tiles_m * tiles_n), block(512);
-            if (abl == 1)
+            if (abl == 3)
+                hipLaunchKernelGGL(limb_gemm_shape_probe, grid, block, 0, ctx->stream, Cpl, (u32)Mp, (u32)Np, nkb);
+            else if (abl == 1)
                 hipLaunchKernelGGL(limb_gemm_kernel<1>, grid, block, 0, ctx->stream, Apl, Bpl, Cpl, (u32)Mp, (u32)Np, nkb,
-                                   tiles_m, tiles_n);
+                                   tiles_m, tiles_n, gm);
             else if (abl == 2)
                 hipLaunchKernelGGL(limb_gemm_kernel<2>, grid, block, 0, ctx->stream, Apl, Bpl, Cpl, (u32)Mp, (u32)Np, nkb,
-                                   tiles_m, tiles_n);
+                                   tiles_m, tiles_n, gm);
             else
                 hipLaunchKernelGGL(limb_gemm_kernel<0>, grid, block, 0, ctx->stream, Apl, Bpl, Cpl, (u32)Mp, (u32)Np, nkb,
-                                   tiles_m, tiles_n);
+                                   tiles_m, tiles_n, gm);
         }
         const u64 total = r * c;
         const u32 grid = (u32)(ceil_div(total, 256) < 4096 ? ceil_div(total, 256) : 4096);
