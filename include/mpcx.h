@@ -224,6 +224,61 @@ int mpcx_snn_msbl1_party_mid(mpcx_ctx *ctx, int party, const int64_t *beta1_j, c
 int mpcx_snn_msbl1_party_finish(mpcx_ctx *ctx, const int64_t *gamma, const int64_t *delta, const int64_t *theta,
                                 uint64_t n, int64_t *B);
 
+/* ---- MyEngine (mpc_engine/MyEngine.cpp): additive shares on parties 0/1, party 2 deals ----
+ * seed0 / seed1 = the streams party 2 shares with party 0 / 1 (its prgs[0] / prgs[1], KEY20 / KEY12, :21-24);
+ * seed2 = that same stream as seen from party 0 / 1 (its prgs[2]); seedS = party 2's self stream; seed01 = the
+ * stream parties 0 and 1 share.  All randomness here is read from the generators' buffers (int_buff / bool_buff
+ * at size-dependent offsets), never popped.
+ * share / share_matrix (:54-89) = mpcx_snn_share_local; reveal / reveal_matrix (:91-143) = mpcx_ring_add;
+ * reveal_L_1 (:809-839) = mpcx_snn_add_L1; reveal_zp (:841-877) = mpcx_snn_add_zp; privateCompare's party 2
+ * (:402-426) = mpcx_snn_pc_helper. */
+/* matrix_mul (:145-219), one round.  dealer: C_j (row-major) is the message to party j.  open: ef = (X-A)|(Y-B)
+ * row-major, the message to the peer.  finish: Z = C + E*B + A*F + party*E*F in layoutZ. */
+int mpcx_my_beaver_dealer_matmul(mpcx_ctx *ctx, uint64_t seed0, uint64_t seed1, uint64_t seedS, uint64_t r, uint64_t l,
+                                 uint64_t c, int64_t *C0, int64_t *C1);
+int mpcx_my_beaver_party_open_matmul(mpcx_ctx *ctx, const int64_t *X, const int64_t *Y, int layout, uint64_t seed2,
+                                     uint64_t r, uint64_t l, uint64_t c, int64_t *ef_out);
+int mpcx_my_beaver_party_finish_matmul(mpcx_ctx *ctx, int party, uint64_t seed2, const int64_t *C, const int64_t *ef_own,
+                                       const int64_t *ef_peer, uint64_t r, uint64_t l, uint64_t c, int layoutZ,
+                                       int64_t *Z);
+/* vector_mul (:221-280), one round; ef = E[n] | F[n] */
+int mpcx_my_beaver_dealer_vecmul(mpcx_ctx *ctx, uint64_t seed0, uint64_t seed1, uint64_t seedS, uint64_t n_total,
+                                 uint64_t i0, uint64_t n, int64_t *C0, int64_t *C1);
+int mpcx_my_beaver_party_open_vecmul(mpcx_ctx *ctx, const int64_t *X, const int64_t *Y, uint64_t seed2, uint64_t n_total,
+                                     uint64_t i0, uint64_t n, int64_t *ef_out);
+int mpcx_my_beaver_party_finish_vecmul(mpcx_ctx *ctx, int party, uint64_t seed2, const int64_t *C, const int64_t *ef_own,
+                                       const int64_t *ef_peer, uint64_t n_total, uint64_t i0, uint64_t n, int64_t *Z);
+/* privateCompare, party 0/1 (:293-357): as SecureNN's without the r = -1 branch (beta != 0 compares against r + 1) */
+int mpcx_my_pc_party(mpcx_ctx *ctx, int party, const uint16_t *xbits, const int8_t *beta, const int64_t *r, uint64_t i0,
+                     uint64_t n, uint64_t seed01, uint16_t *d_out);
+/* msb (:442-597), three rounds, the result is an XOR share (one byte per element).
+ *  helper_deal (party 2, before round 1): message to party j = xlsb_j[n] | xbits_j[n][64]
+ *  party_open (party 0/1, before round 1): r_j = (buf2[k] % L_1) +L (2a +L 2a), the message to the peer
+ *  party_pc_inputs: the plaintext privateCompare inputs of round 2 (beta = boolbuf01[k], R = r_peer +L r_own)
+ *  helper_beta (party 2, after round 2): XOR shares of beta', the round-3 messages
+ *  party_finish (after round 3) */
+int mpcx_my_msb_helper_deal(mpcx_ctx *ctx, uint64_t seed0, uint64_t seed1, uint64_t seedS, uint64_t i0, uint64_t n,
+                            int8_t *xlsb0, uint16_t *xbits0, int8_t *xlsb1, uint16_t *xbits1);
+int mpcx_my_msb_helper_beta(mpcx_ctx *ctx, const int8_t *beta1_plain, uint64_t n_total, uint64_t i0, uint64_t n,
+                            uint64_t seedS, int8_t *b0, int8_t *b1);
+int mpcx_my_msb_party_open(mpcx_ctx *ctx, const int64_t *A, uint64_t seed2, uint64_t i0, uint64_t n, int64_t *r_out);
+int mpcx_my_msb_party_pc_inputs(mpcx_ctx *ctx, const int64_t *r_own, const int64_t *r_peer, uint64_t i0, uint64_t n,
+                                uint64_t seed01, int8_t *beta_out, int64_t *R_out);
+int mpcx_my_msb_party_finish(mpcx_ctx *ctx, int party, const int8_t *beta1_j, const int8_t *beta0, const int8_t *xlsb_j,
+                             const int64_t *R, uint64_t n, int8_t *B);
+/* bit_inject (:599-772), one round.  dealer: message to party j = V_j|W_j|S_j|T_j.  pre (party 0/1): message to the
+ * peer = y_j[n] | c_j[n bytes].  post: Z_j. */
+int mpcx_my_bit_inject_dealer(mpcx_ctx *ctx, uint64_t seed0, uint64_t seed1, uint64_t seedS, uint64_t n_total, uint64_t i0,
+                              uint64_t n, int64_t *V0, int64_t *W0, int64_t *S0, int64_t *T0, int64_t *V1, int64_t *W1,
+                              int64_t *S1, int64_t *T1);
+int mpcx_my_bit_inject_party_pre(mpcx_ctx *ctx, const int64_t *X, const int8_t *A, uint64_t seed2, uint64_t i0, uint64_t n,
+                                 int64_t *y_out, int8_t *c_out);
+int mpcx_my_bit_inject_party_post(mpcx_ctx *ctx, int party, uint64_t seed2, uint64_t i0, uint64_t n, const int64_t *y_own,
+                                  const int8_t *c_own, const int64_t *y_peer, const int8_t *c_peer, const int64_t *V,
+                                  const int64_t *W, const int64_t *S, const int64_t *T, int64_t *Z);
+/* reveal_vec_bools (:777-807): out = a ^ b, one byte per boolean */
+int mpcx_xor_bools(mpcx_ctx *ctx, const int8_t *a, const int8_t *b, int8_t *out, uint64_t n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -108,6 +108,9 @@ int prg_fill_buff_mod67(mpcx_ctx *ctx, u64 seed, u64 lcg, u64 first, u64 count, 
 int prg_buff_mod67_cached(mpcx_ctx *ctx, u64 seed, u64 lcg, u64 first, u64 count, int zero_to_one, u64 ws_total,
                           u64 ws_offset, const u8 **out);
 void prg_rand_cache_clear(mpcx_ctx *ctx);
+// Z_67 sharing of the 64 bits of v[i]: first[i][k] = rnd[64 i + k] (one byte, already % 67),
+// second[i][k] = (bit_k(v[i]) + 67 - first[i][k]) % 67; first / second are 16-byte aligned
+int snn_bit_share_launch(mpcx_ctx *ctx, const u64 *v, const u8 *rnd, u64 n, u16 *first, u16 *second);
 static inline u64 ceil_div(u64 a, u64 b) { return (a + b - 1) / b; }
 
 // Z (+)= [A_1 | A_2 | ..] * [B_1 (+Bplus_1) ; B_2 ; ..] (+ add - sub): a ring product whose K dimension is the

@@ -1,0 +1,281 @@
+// Per-party local segments of MyEngine (mpc_engine/MyEngine.cpp) as HIP kernels.
+//
+// MyEngine keeps two-party additive shares on parties 0/1 and uses party 2 as a dealer.  Its correlated
+// randomness is read from the *buffers* of the pairwise generators: party 2's prgs[0] / prgs[1] (KEY20 / KEY12,
+// MyEngine.cpp:21-24) are the streams parties 0 / 1 hold as prgs[2] (:11-19), so both ends see the same
+// int_buff / bool_buff words and only the dealer's correction terms travel.  The buffers are regenerated on the
+// device for any index.  share / reveal / privateCompare's helper role are the SecureNN entry points.
+#include "mpcx_internal.h"
+
+namespace {
+
+constexpr u64 L_1 = ~0ull; // utils/util.hpp:12
+
+// MyEngine.cpp:39-52
+__device__ inline u64 add_L_1(u64 a, u64 b) {
+    const u64 c = a + b;
+    const u64 carry = c < a;
+    return (c + carry) % L_1;
+}
+
+template <class F> __global__ __launch_bounds__(256) void ew_kernel(u64 n, F f) {
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256) f(i);
+}
+template <class F> int ew_launch(mpcx_ctx *ctx, u64 n, F f) {
+    if (n == 0) return 0;
+    u64 blocks = ceil_div(n, 256);
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(ew_kernel<F>, dim3((u32)blocks), dim3(256), 0, ctx->stream, n, f);
+    MPCX_LAUNCH_CHECK();
+    return 0;
+}
+
+// scratch from the context's block pool; handed back when the call returns (every use is ordered on the stream)
+struct Tmp {
+    mpcx_ctx *ctx;
+    void *p = nullptr;
+    explicit Tmp(mpcx_ctx *c) : ctx(c) {}
+    int get(u64 bytes) { return mpcx_malloc(ctx, bytes, &p); }
+    ~Tmp() {
+        if (p) (void)mpcx_free(ctx, p);
+    }
+    Tmp(const Tmp &) = delete;
+    Tmp &operator=(const Tmp &) = delete;
+};
+
+// int_buff[first .. first+count) of a stream (and bool_buff into `bools` when given)
+inline int buff(mpcx_ctx *ctx, u64 seed, u64 first, u64 count, u64 *ints, i8 *bools = nullptr) {
+    return prg_fill_words(ctx, seed, 0, 2 * first, count, 2, (i64 *)ints, bools);
+}
+
+} // namespace
+
+extern "C" {
+
+// ---- Beaver matrix product (MyEngine.cpp:145-219), one round
+int mpcx_my_beaver_dealer_matmul(mpcx_ctx *ctx, uint64_t seed0, uint64_t seed1, uint64_t seedS, uint64_t r, uint64_t l,
+                                 uint64_t c, int64_t *C0, int64_t *C1) {
+    MPCX_REQUIRE(C0 && C1, "mpcx_my_beaver_dealer_matmul: NULL pointer");
+    MPCX_REQUIRE(r && l && c, "mpcx_my_beaver_dealer_matmul: empty shape");
+    const u64 na = r * l, nb = l * c, nc = r * c;
+    Tmp t(ctx);
+    MPCX_TRY(t.get(8 * (2 * na + 2 * nb)));
+    u64 *As = (u64 *)t.p, *A1 = As + na, *B0 = A1 + na, *B1 = B0 + nb;
+    // :157-171: A_j then B_j are consecutive slices of stream j's buffer, so one fill per stream covers both
+    MPCX_TRY(buff(ctx, seed0, 0, na, As));
+    MPCX_TRY(buff(ctx, seed1, 0, na, A1));
+    MPCX_TRY(buff(ctx, seed0, na, nb, B0));
+    MPCX_TRY(buff(ctx, seed1, na, nb, B1));
+    MPCX_TRY(buff(ctx, seedS, 0, nc, (u64 *)C0)); // :173-176
+    MPCX_TRY(ew_launch(ctx, na, [=] __device__(u64 i) { As[i] += A1[i]; }));
+    // C_1 = (A_0 + A_1)(B_0 + B_1) - C_0  (:178)
+    GemmPart p{(const i64 *)As, (const i64 *)B0, (const i64 *)B1};
+    return ring_gemm_parts(ctx, &p, 1, r, l, c, 0, 0, nullptr, C0, C1, 0, 0);
+}
+
+int mpcx_my_beaver_party_open_matmul(mpcx_ctx *ctx, const int64_t *X, const int64_t *Y, int layout, uint64_t seed2,
+                                     uint64_t r, uint64_t l, uint64_t c, int64_t *ef_out) {
+    MPCX_REQUIRE(X && Y && ef_out, "mpcx_my_beaver_party_open_matmul: NULL pointer");
+    MPCX_REQUIRE(r && l && c, "mpcx_my_beaver_party_open_matmul: empty shape");
+    const u64 na = r * l, nb = l * c;
+    Tmp t(ctx);
+    MPCX_TRY(t.get(8 * (na + nb)));
+    MPCX_TRY(buff(ctx, seed2, 0, na + nb, (u64 *)t.p)); // A | B (:187-198)
+    // E = X - A, F = Y - B, row-major (:201-205): the same arithmetic as SecureNN's opening
+    return mpcx_snn_beaver_party_open_matmul(ctx, X, Y, layout, (const i64 *)t.p, r, l, c, ef_out);
+}
+
+int mpcx_my_beaver_party_finish_matmul(mpcx_ctx *ctx, int party, uint64_t seed2, const int64_t *C, const int64_t *ef_own,
+                                       const int64_t *ef_peer, uint64_t r, uint64_t l, uint64_t c, int layoutZ,
+                                       int64_t *Z) {
+    MPCX_REQUIRE(party == 0 || party == 1, "mpcx_my_beaver_party_finish_matmul: party %d", party);
+    MPCX_REQUIRE(C && ef_own && ef_peer && Z, "mpcx_my_beaver_party_finish_matmul: NULL pointer");
+    MPCX_REQUIRE(r && l && c, "mpcx_my_beaver_party_finish_matmul: empty shape");
+    const u64 na = r * l, nb = l * c, nc = r * c;
+    Tmp t(ctx);
+    MPCX_TRY(t.get(8 * (na + nb + nc)));
+    u64 *triple = (u64 *)t.p; // A | B | C
+    MPCX_TRY(buff(ctx, seed2, 0, na + nb, triple));
+    MPCX_TRY(mpcx_d2d(ctx, triple + na + nb, C, 8 * nc));
+    // Z = C + E*B + A*F + E*F*party (:217)
+    return mpcx_snn_beaver_party_finish_matmul(ctx, party, (const i64 *)triple, ef_own, ef_peer, r, l, c, layoutZ, Z);
+}
+
+// ---- Beaver vector product (:221-280), one round
+int mpcx_my_beaver_dealer_vecmul(mpcx_ctx *ctx, uint64_t seed0, uint64_t seed1, uint64_t seedS, uint64_t n_total,
+                                 uint64_t i0, uint64_t n, int64_t *C0, int64_t *C1) {
+    if (n == 0) return 0;
+    MPCX_REQUIRE(C0 && C1, "mpcx_my_beaver_dealer_vecmul: NULL pointer");
+    MPCX_REQUIRE(i0 + n <= n_total, "mpcx_my_beaver_dealer_vecmul: range outside the vector");
+    Tmp t(ctx);
+    MPCX_TRY(t.get(32 * n));
+    u64 *A0 = (u64 *)t.p, *A1 = A0 + n, *B0 = A1 + n, *B1 = B0 + n;
+    MPCX_TRY(buff(ctx, seed0, i0, n, A0)); // :238-239
+    MPCX_TRY(buff(ctx, seed1, i0, n, A1));
+    MPCX_TRY(buff(ctx, seed0, n_total + i0, n, B0));
+    MPCX_TRY(buff(ctx, seed1, n_total + i0, n, B1));
+    MPCX_TRY(buff(ctx, seedS, i0, n, (u64 *)C0)); // :244
+    const u64 *c0 = (const u64 *)C0;
+    return ew_launch(ctx, n, [=] __device__(u64 k) { C1[k] = (i64)((A0[k] + A1[k]) * (B0[k] + B1[k]) - c0[k]); }); // :245
+}
+int mpcx_my_beaver_party_open_vecmul(mpcx_ctx *ctx, const int64_t *X, const int64_t *Y, uint64_t seed2, uint64_t n_total,
+                                     uint64_t i0, uint64_t n, int64_t *ef_out) {
+    if (n == 0) return 0;
+    MPCX_REQUIRE(X && Y && ef_out, "mpcx_my_beaver_party_open_vecmul: NULL pointer");
+    MPCX_REQUIRE(i0 + n <= n_total, "mpcx_my_beaver_party_open_vecmul: range outside the vector");
+    Tmp t(ctx);
+    MPCX_TRY(t.get(16 * n));
+    u64 *A = (u64 *)t.p, *B = A + n;
+    MPCX_TRY(buff(ctx, seed2, i0, n, A)); // :258-259
+    MPCX_TRY(buff(ctx, seed2, n_total + i0, n, B));
+    return ew_launch(ctx, n, [=] __device__(u64 k) {
+        ef_out[k] = (i64)((u64)X[k] - A[k]); // :262-263
+        ef_out[n + k] = (i64)((u64)Y[k] - B[k]);
+    });
+}
+int mpcx_my_beaver_party_finish_vecmul(mpcx_ctx *ctx, int party, uint64_t seed2, const int64_t *C, const int64_t *ef_own,
+                                       const int64_t *ef_peer, uint64_t n_total, uint64_t i0, uint64_t n, int64_t *Z) {
+    if (n == 0) return 0;
+    MPCX_REQUIRE(party == 0 || party == 1, "mpcx_my_beaver_party_finish_vecmul: party %d", party);
+    MPCX_REQUIRE(C && ef_own && ef_peer && Z, "mpcx_my_beaver_party_finish_vecmul: NULL pointer");
+    MPCX_REQUIRE(i0 + n <= n_total, "mpcx_my_beaver_party_finish_vecmul: range outside the vector");
+    Tmp t(ctx);
+    MPCX_TRY(t.get(16 * n));
+    u64 *A = (u64 *)t.p, *B = A + n;
+    MPCX_TRY(buff(ctx, seed2, i0, n, A));
+    MPCX_TRY(buff(ctx, seed2, n_total + i0, n, B));
+    const u64 pid = (u64)party;
+    return ew_launch(ctx, n, [=] __device__(u64 k) {
+        const u64 E = (u64)ef_peer[k] + (u64)ef_own[k], F = (u64)ef_peer[n + k] + (u64)ef_own[n + k]; // :276-277
+        Z[k] = (i64)((u64)C[k] + E * B[k] + A[k] * F + E * F * pid);                                  // :278
+    });
+}
+
+// ---- msb (:442-597), three rounds, boolean (XOR) output shares
+int mpcx_my_msb_helper_deal(mpcx_ctx *ctx, uint64_t seed0, uint64_t seed1, uint64_t seedS, uint64_t i0, uint64_t n,
+                            int8_t *xlsb0, uint16_t *xbits0, int8_t *xlsb1, uint16_t *xbits1) {
+    if (n == 0) return 0;
+    MPCX_REQUIRE(xlsb0 && xbits0 && xlsb1 && xbits1, "mpcx_my_msb_helper_deal: NULL pointer");
+    MPCX_REQUIRE(((uintptr_t)xbits0 & 15) == 0 && ((uintptr_t)xbits1 & 15) == 0, "mpcx_my_msb_helper_deal: xbits must be 16-byte aligned");
+    const u8 *rnd;
+    ctx->rand_tick++;
+    MPCX_TRY(prg_buff_mod67_cached(ctx, seedS, 0, 64 * i0, 64 * n, 0, 64 * n, 0, &rnd)); // :495-496
+    Tmp t(ctx);
+    MPCX_TRY(t.get(24 * n));
+    u64 *w0 = (u64 *)t.p, *w1 = w0 + n, *xv = w1 + n;
+    MPCX_TRY(buff(ctx, seed0, i0, n, w0)); // :483
+    MPCX_TRY(buff(ctx, seed1, i0, n, w1));
+    MPCX_TRY(prg_fill_words(ctx, seedS, 0, 2 * i0, n, 2, nullptr, xlsb0)); // :490
+    MPCX_TRY(ew_launch(ctx, n, [=] __device__(u64 k) {
+        const u64 x = add_L_1(w0[k] % L_1, w1[k] % L_1); // :488
+        xv[k] = x;
+        xlsb1[k] = (i8)((i8)(x & 1) ^ xlsb0[k]); // :491
+    }));
+    return snn_bit_share_launch(ctx, xv, rnd, n, xbits0, xbits1); // :494-499
+}
+int mpcx_my_msb_helper_beta(mpcx_ctx *ctx, const int8_t *beta1_plain, uint64_t n_total, uint64_t i0, uint64_t n,
+                            uint64_t seedS, int8_t *b0, int8_t *b1) {
+    if (n == 0) return 0;
+    MPCX_REQUIRE(beta1_plain && b0 && b1, "mpcx_my_msb_helper_beta: NULL pointer");
+    MPCX_REQUIRE(i0 + n <= n_total, "mpcx_my_msb_helper_beta: range outside the vector");
+    MPCX_TRY(prg_fill_words(ctx, seedS, 0, 2 * (n_total + i0), n, 2, nullptr, b0)); // :519
+    return ew_launch(ctx, n, [=] __device__(u64 k) { b1[k] = (i8)(beta1_plain[k] ^ b0[k]); }); // :520
+}
+int mpcx_my_msb_party_open(mpcx_ctx *ctx, const int64_t *A, uint64_t seed2, uint64_t i0, uint64_t n, int64_t *r_out) {
+    if (n == 0) return 0;
+    MPCX_REQUIRE(A && r_out, "mpcx_my_msb_party_open: NULL pointer");
+    Tmp t(ctx);
+    MPCX_TRY(t.get(8 * n));
+    u64 *w = (u64 *)t.p;
+    MPCX_TRY(buff(ctx, seed2, i0, n, w)); // :541
+    return ew_launch(ctx, n, [=] __device__(u64 k) {
+        const u64 d = 2 * (u64)A[k];   // :446
+        const u64 y = add_L_1(d, d);   // :451
+        r_out[k] = (i64)add_L_1(w[k] % L_1, y); // :548
+    });
+}
+int mpcx_my_msb_party_pc_inputs(mpcx_ctx *ctx, const int64_t *r_own, const int64_t *r_peer, uint64_t i0, uint64_t n,
+                                uint64_t seed01, int8_t *beta_out, int64_t *R_out) {
+    // beta = boolbuf01[k] (:544), R = r_peer +L r_own (:558): what SecureNN's msb_L_1 feeds privateCompare
+    return mpcx_snn_msbl1_party_pc_inputs(ctx, r_own, r_peer, i0, n, seed01, beta_out, R_out);
+}
+int mpcx_my_msb_party_finish(mpcx_ctx *ctx, int party, const int8_t *beta1_j, const int8_t *beta0, const int8_t *xlsb_j,
+                             const int64_t *R, uint64_t n, int8_t *B) {
+    MPCX_REQUIRE(party == 0 || party == 1, "mpcx_my_msb_party_finish: party %d", party);
+    MPCX_REQUIRE((beta1_j && beta0 && xlsb_j && R && B) || n == 0, "mpcx_my_msb_party_finish: NULL pointer");
+    return ew_launch(ctx, n, [=] __device__(u64 k) {
+        const i8 b = party == 0 ? beta1_j[k] : (i8)(beta1_j[k] ^ beta0[k]); // :578
+        const i8 r0 = (i8)((u64)R[k] % 2);                                 // :579
+        B[k] = party == 1 ? (i8)(b ^ xlsb_j[k]) : (i8)(b ^ xlsb_j[k] ^ r0); // :580
+    });
+}
+
+// ---- bit_inject (:599-772), one round
+int mpcx_my_bit_inject_dealer(mpcx_ctx *ctx, uint64_t seed0, uint64_t seed1, uint64_t seedS, uint64_t n_total, uint64_t i0,
+                              uint64_t n, int64_t *V0, int64_t *W0, int64_t *S0, int64_t *T0, int64_t *V1, int64_t *W1,
+                              int64_t *S1, int64_t *T1) {
+    if (n == 0) return 0;
+    MPCX_REQUIRE(V0 && W0 && S0 && T0 && V1 && W1 && S1 && T1, "mpcx_my_bit_inject_dealer: NULL pointer");
+    MPCX_REQUIRE(i0 + n <= n_total, "mpcx_my_bit_inject_dealer: range outside the vector");
+    Tmp t(ctx);
+    MPCX_TRY(t.get(18 * n + 64));
+    u64 *U0 = (u64 *)t.p, *U1 = U0 + n;
+    i8 *B0 = (i8 *)(U1 + n), *B1 = B0 + n;
+    MPCX_TRY(buff(ctx, seed0, i0, n, U0, B0)); // :711-712
+    MPCX_TRY(buff(ctx, seed1, i0, n, U1, B1));
+    MPCX_TRY(buff(ctx, seedS, i0, n, (u64 *)V0));               // :730
+    MPCX_TRY(buff(ctx, seedS, n_total + i0, n, (u64 *)W0));     // :733
+    MPCX_TRY(buff(ctx, seedS, 2 * n_total + i0, n, (u64 *)S0)); // :736
+    MPCX_TRY(buff(ctx, seedS, 3 * n_total + i0, n, (u64 *)T0)); // :739
+    return ew_launch(ctx, n, [=] __device__(u64 i) {
+        const i8 b = (i8)(B0[i] ^ B1[i]); // :717
+        const u64 u = U0[i] + U1[i];      // :718
+        V1[i] = (i64)((u64)(i64)b * u - (u64)V0[i]);
+        W1[i] = (i64)((u64)(i64)(1 ^ b) * u - (u64)W0[i]);
+        S1[i] = (i64)((u64)(i64)(B0[i] * B1[i]) - (u64)S0[i]);
+        T1[i] = (i64)((u64)(i64)(B0[i] * (1 ^ B1[i])) - (u64)T0[i]);
+    });
+}
+int mpcx_my_bit_inject_party_pre(mpcx_ctx *ctx, const int64_t *X, const int8_t *A, uint64_t seed2, uint64_t i0, uint64_t n,
+                                 int64_t *y_out, int8_t *c_out) {
+    if (n == 0) return 0;
+    MPCX_REQUIRE(X && A && y_out && c_out, "mpcx_my_bit_inject_party_pre: NULL pointer");
+    Tmp t(ctx);
+    MPCX_TRY(t.get(9 * n + 64));
+    u64 *U = (u64 *)t.p;
+    i8 *B = (i8 *)(U + n);
+    MPCX_TRY(buff(ctx, seed2, i0, n, U, B)); // :610-611
+    return ew_launch(ctx, n, [=] __device__(u64 i) {
+        y_out[i] = (i64)((u64)X[i] - U[i]); // :619
+        c_out[i] = (i8)(B[i] ^ A[i]);       // :617
+    });
+}
+int mpcx_my_bit_inject_party_post(mpcx_ctx *ctx, int party, uint64_t seed2, uint64_t i0, uint64_t n, const int64_t *y_own,
+                                  const int8_t *c_own, const int64_t *y_peer, const int8_t *c_peer, const int64_t *V,
+                                  const int64_t *W, const int64_t *S, const int64_t *T, int64_t *Z) {
+    if (n == 0) return 0;
+    MPCX_REQUIRE(party == 0 || party == 1, "mpcx_my_bit_inject_party_post: party %d", party);
+    MPCX_REQUIRE(y_own && c_own && y_peer && c_peer && V && W && S && T && Z, "mpcx_my_bit_inject_party_post: NULL pointer");
+    Tmp t(ctx);
+    MPCX_TRY(t.get(n + 64));
+    i8 *B = (i8 *)t.p;
+    MPCX_TRY(prg_fill_words(ctx, seed2, 0, 2 * i0, n, 2, nullptr, B)); // :611
+    const u64 pid = (u64)party;
+    return ew_launch(ctx, n, [=] __device__(u64 i) {
+        const u64 y = (u64)y_peer[i] + (u64)y_own[i]; // :634
+        const i8 cp = (i8)(c_peer[i] ^ c_own[i]);     // :635
+        const u64 bj = (u64)(i64)B[i];
+        if (cp == 0)
+            Z[i] = (i64)((u64)V[i] + y * (bj - 2 * (u64)S[i])); // :654
+        else
+            Z[i] = (i64)((u64)W[i] + y * ((pid ^ bj) - 2 * (u64)T[i])); // :658
+    });
+}
+
+// reveal_vec_bools (:777-807): XOR of two byte-per-boolean shares
+int mpcx_xor_bools(mpcx_ctx *ctx, const int8_t *a, const int8_t *b, int8_t *out, uint64_t n) {
+    MPCX_REQUIRE((a && b && out) || n == 0, "mpcx_xor_bools: NULL pointer");
+    return ew_launch(ctx, n, [=] __device__(u64 i) { out[i] = (i8)(a[i] ^ b[i]); });
+}
+
+} // extern "C"

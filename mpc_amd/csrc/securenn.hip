@@ -40,7 +40,9 @@ struct u16x8 {
 
 // privateCompare, party 0/1 (SecurennEngine.cpp:543-592).  One piece = 8 bit positions of one element.
 // S / U: one byte per value, already reduced mod 67 with 0 -> 1 (:523-534).
-__global__ __launch_bounds__(256) void pc_party_kernel(int party, const uint4 *__restrict__ xbits, const i8 *__restrict__ beta,
+// variant 1 = MyEngine::privateCompare (MyEngine.cpp:316-353): the same two formulas, chosen by beta == 0 alone
+// (any other beta compares against r + 1, which wraps to 0 for r = -1); U is not read.
+__global__ __launch_bounds__(256) void pc_party_kernel(int party, int variant, const uint4 *__restrict__ xbits, const i8 *__restrict__ beta,
                                                        const i64 *__restrict__ r, const u64 *__restrict__ S,
                                                        const u64 *__restrict__ U, u64 n, uint4 *__restrict__ d_out) {
     const u64 pieces = n * 8;
@@ -63,7 +65,7 @@ __global__ __launch_bounds__(256) void pc_party_kernel(int party, const uint4 *_
             bt = beta[i];
         }
         const u64 tv = rv + 1;
-        const int mode = (bt == 0) ? 0 : ((bt == 1 && rv != ~0ull) ? 1 : 2);
+        const int mode = (bt == 0) ? 0 : ((variant == 1 || (bt == 1 && rv != ~0ull)) ? 1 : 2);
         u32 wv[8], cv[8];
         u32 tot = 0;
         if (mode != 2) {
@@ -181,6 +183,13 @@ __device__ inline ScRand sc_rand(u64 w0, u64 w1) {
 }
 
 } // namespace
+
+int snn_bit_share_launch(mpcx_ctx *ctx, const u64 *v, const u8 *rnd, u64 n, u16 *first, u16 *second) {
+    hipLaunchKernelGGL(bit_share_kernel, dim3(grid_for(8 * n)), dim3(256), 0, ctx->stream, v, (const u64 *)rnd, n,
+                       (uint4 *)first, (uint4 *)second);
+    MPCX_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" {
 
@@ -324,8 +333,23 @@ int mpcx_snn_pc_party(mpcx_ctx *ctx, int party, const uint16_t *xbits, const int
     MPCX_TRY(prg_buff_mod67_cached(ctx, seed01, 0, 64 * i0, 64 * n, 1, 128 * n, 0, &S));                     // :523,525-529
     MPCX_TRY(prg_buff_mod67_cached(ctx, seed01, 0, 64 * n_total + 64 * i0, 64 * n, 1, 128 * n, 64 * n, &U)); // :524,530-534
     ProfScope ps(ctx, PROF_PC_PARTY);
-    hipLaunchKernelGGL(pc_party_kernel, dim3(grid_for(8 * n)), dim3(256), 0, ctx->stream, party, (const uint4 *)xbits, beta,
+    hipLaunchKernelGGL(pc_party_kernel, dim3(grid_for(8 * n)), dim3(256), 0, ctx->stream, party, 0, (const uint4 *)xbits, beta,
                        r, (const u64 *)S, (const u64 *)U, n, (uint4 *)d_out);
+    MPCX_LAUNCH_CHECK();
+    return 0;
+}
+int mpcx_my_pc_party(mpcx_ctx *ctx, int party, const uint16_t *xbits, const int8_t *beta, const int64_t *r, uint64_t i0,
+                     uint64_t n, uint64_t seed01, uint16_t *d_out) {
+    if (n == 0) return 0;
+    MPCX_REQUIRE(party == 0 || party == 1, "mpcx_my_pc_party: party %d", party);
+    MPCX_REQUIRE(xbits && beta && r && d_out, "mpcx_my_pc_party: NULL pointer");
+    MPCX_REQUIRE(((uintptr_t)xbits & 15) == 0 && ((uintptr_t)d_out & 15) == 0, "mpcx_my_pc_party: xbits/d_out must be 16-byte aligned");
+    const u8 *S;
+    ctx->rand_tick++;
+    MPCX_TRY(prg_buff_mod67_cached(ctx, seed01, 0, 64 * i0, 64 * n, 1, 64 * n, 0, &S)); // MyEngine.cpp:298-308
+    ProfScope ps(ctx, PROF_PC_PARTY);
+    hipLaunchKernelGGL(pc_party_kernel, dim3(grid_for(8 * n)), dim3(256), 0, ctx->stream, party, 1, (const uint4 *)xbits, beta,
+                       r, (const u64 *)S, (const u64 *)nullptr, n, (uint4 *)d_out);
     MPCX_LAUNCH_CHECK();
     return 0;
 }

@@ -840,4 +840,241 @@ int orc_ring_shl1(const i64 *a, i64 *out, u64 n) {
     return 0;
 }
 
+// ================================================================ MyEngine
+// mpc_engine/MyEngine.cpp: two-party additive shares (parties 0/1) with party 2 as the dealer; every product,
+// msb and bit_inject costs few rounds because the correlated randomness comes from the *buffers* of the
+// pairwise streams: party 2's prgs[0] / prgs[1] are the streams it shares with party 0 / 1 (KEY20 / KEY12,
+// :21-24) and party j's prgs[2] is that same stream (:11-19), so both sides read identical int_buff words.
+// share / share_matrix (:54-89) are orc_snn_share_local; reveal* (:91-143, :777-877) are orc_ring_add,
+// orc_snn_add_L1, orc_snn_add_zp and a byte XOR.
+
+// matrix_mul, party 2 (:152-184): A_j = buf_j[k*l + ..], B_j = buf_j[r*l + ..], C_0 = bufS[i*c + k],
+// C_1 = (A_0 + A_1)(B_0 + B_1) - C_0; C_j (row-major) is the message to party j.
+int orc_my_beaver_dealer_matmul(u64 seed0, u64 seed1, u64 seedS, u64 r, u64 l, u64 c, i64 *C0, i64 *C1) {
+    const u64 na = r * l, nb = l * c, nc = r * c;
+    std::vector<i64> A0(na), A1(na), B0(nb), B1(nb), As(na), Bs(nb), Cs(nc);
+    orc_prg_fill_buff(seed0, 0, 0, na, A0.data(), nullptr);
+    orc_prg_fill_buff(seed1, 0, 0, na, A1.data(), nullptr);
+    orc_prg_fill_buff(seed0, 0, na, nb, B0.data(), nullptr);
+    orc_prg_fill_buff(seed1, 0, na, nb, B1.data(), nullptr);
+    orc_prg_fill_buff(seedS, 0, 0, nc, C0, nullptr);
+    for (u64 i = 0; i < na; i++) As[i] = (i64)((u64)A0[i] + (u64)A1[i]);
+    for (u64 i = 0; i < nb; i++) Bs[i] = (i64)((u64)B0[i] + (u64)B1[i]);
+    ring_gemm(As.data(), Bs.data(), Cs.data(), r, l, c, 0, 0, 0, 0);
+    for (u64 i = 0; i < nc; i++) C1[i] = (i64)((u64)Cs[i] - (u64)C0[i]);
+    return 0;
+}
+// party 0/1 before the round (:187-205): A_j = buf2[k*l + ..], B_j = buf2[r*l + ..]; ef_out = (X - A) | (Y - B), row-major
+int orc_my_beaver_party_open_matmul(const i64 *X, const i64 *Y, int layout, u64 seed2, u64 r, u64 l, u64 c, i64 *ef_out) {
+    const u64 na = r * l, nb = l * c;
+    std::vector<i64> A(na), B(nb);
+    orc_prg_fill_buff(seed2, 0, 0, na, A.data(), nullptr);
+    orc_prg_fill_buff(seed2, 0, na, nb, B.data(), nullptr);
+    for (u64 i = 0; i < r; i++)
+        for (u64 k = 0; k < l; k++) ef_out[i * l + k] = (i64)(ld(X, r, l, layout, i, k) - (u64)A[i * l + k]);
+    for (u64 i = 0; i < l; i++)
+        for (u64 k = 0; k < c; k++) ef_out[na + i * c + k] = (i64)(ld(Y, l, c, layout, i, k) - (u64)B[i * c + k]);
+    return 0;
+}
+// party 0/1 after the round (:208-217): Z = C + E*B + A*F + E*F*party
+int orc_my_beaver_party_finish_matmul(int party, u64 seed2, const i64 *C, const i64 *ef_own, const i64 *ef_peer, u64 r,
+                                      u64 l, u64 c, int layoutZ, i64 *Z) {
+    const u64 na = r * l, nb = l * c, nc = r * c;
+    std::vector<i64> A(na), B(nb), E(na), F(nb), T(nc);
+    orc_prg_fill_buff(seed2, 0, 0, na, A.data(), nullptr);
+    orc_prg_fill_buff(seed2, 0, na, nb, B.data(), nullptr);
+    for (u64 i = 0; i < na; i++) E[i] = (i64)((u64)ef_peer[i] + (u64)ef_own[i]);
+    for (u64 i = 0; i < nb; i++) F[i] = (i64)((u64)ef_peer[na + i] + (u64)ef_own[na + i]);
+    for (u64 i = 0; i < nc; i++) T[i] = C[i];
+    ring_gemm(E.data(), B.data(), T.data(), r, l, c, 0, 0, 0, 1);
+    ring_gemm(A.data(), F.data(), T.data(), r, l, c, 0, 0, 0, 1);
+    if (party) ring_gemm(E.data(), F.data(), T.data(), r, l, c, 0, 0, 0, 1);
+    for (u64 i = 0; i < r; i++)
+        for (u64 k = 0; k < c; k++) Z[layoutZ ? k * r + i : i * c + k] = T[i * c + k];
+    return 0;
+}
+// vector_mul, party 2 (:226-252): A_j[k] = buf_j[k], B_j[k] = buf_j[k + n], C_0[k] = bufS[k]; (n_total, i0): a range
+int orc_my_beaver_dealer_vecmul(u64 seed0, u64 seed1, u64 seedS, u64 n_total, u64 i0, u64 n, i64 *C0, i64 *C1) {
+    std::vector<i64> A0(n), A1(n), B0(n), B1(n);
+    orc_prg_fill_buff(seed0, 0, i0, n, A0.data(), nullptr);
+    orc_prg_fill_buff(seed1, 0, i0, n, A1.data(), nullptr);
+    orc_prg_fill_buff(seed0, 0, n_total + i0, n, B0.data(), nullptr);
+    orc_prg_fill_buff(seed1, 0, n_total + i0, n, B1.data(), nullptr);
+    orc_prg_fill_buff(seedS, 0, i0, n, C0, nullptr);
+    for (u64 k = 0; k < n; k++)
+        C1[k] = (i64)(((u64)A0[k] + (u64)A1[k]) * ((u64)B0[k] + (u64)B1[k]) - (u64)C0[k]);
+    return 0;
+}
+// party 0/1 before the round (:255-266): ef_out = (X - A)[n] | (Y - B)[n]
+int orc_my_beaver_party_open_vecmul(const i64 *X, const i64 *Y, u64 seed2, u64 n_total, u64 i0, u64 n, i64 *ef_out) {
+    std::vector<i64> A(n), B(n);
+    orc_prg_fill_buff(seed2, 0, i0, n, A.data(), nullptr);
+    orc_prg_fill_buff(seed2, 0, n_total + i0, n, B.data(), nullptr);
+    for (u64 k = 0; k < n; k++) {
+        ef_out[k] = (i64)((u64)X[k] - (u64)A[k]);
+        ef_out[n + k] = (i64)((u64)Y[k] - (u64)B[k]);
+    }
+    return 0;
+}
+// party 0/1 after the round (:269-278)
+int orc_my_beaver_party_finish_vecmul(int party, u64 seed2, const i64 *C, const i64 *ef_own, const i64 *ef_peer,
+                                      u64 n_total, u64 i0, u64 n, i64 *Z) {
+    std::vector<i64> A(n), B(n);
+    orc_prg_fill_buff(seed2, 0, i0, n, A.data(), nullptr);
+    orc_prg_fill_buff(seed2, 0, n_total + i0, n, B.data(), nullptr);
+    for (u64 k = 0; k < n; k++) {
+        const u64 E = (u64)ef_peer[k] + (u64)ef_own[k], F = (u64)ef_peer[n + k] + (u64)ef_own[n + k];
+        Z[k] = (i64)((u64)C[k] + E * (u64)B[k] + (u64)A[k] * F + E * F * (u64)party);
+    }
+    return 0;
+}
+// privateCompare, party 0/1 (:293-357): s_k = (u16)buf01[64 i + k] % 67 (0 -> 1); beta = 0 compares against the
+// bits of r, any other beta against the bits of r + 1 (no r = -1 branch: inputs are promised in [0, 2^64 - 2]).
+int orc_my_pc_party(int party, const u16 *xbits, const i8 *beta, const i64 *r, u64 i0, u64 n, u64 seed01, u16 *d_out) {
+    BuffReader rs(seed01, 64 * i0);
+    const u64 party_id = (u64)party;
+    for (u64 i = 0; i < n; i++) {
+        u16 S[64], C[64], W[64], R[64], T[64];
+        for (int k = 0; k < 64; k++) {
+            S[k] = (u16)rs.next_int();
+            S[k] = S[k] % P;
+            if (0 == S[k]) S[k] = 1;
+            R[k] = (u16)(((u64)r[i] >> k) & 1);
+            T[k] = (u16)((((u64)r[i] + 1) >> k) & 1);
+        }
+        const u16 *X = xbits + 64 * i;
+        u16 sum_w = 0;
+        for (int k = 63; k != -1; k--) {
+            if (beta[i] == 0) {
+                C[k] = (u16)((X[k] * (P - 1)) % P + (u16)party_id * R[k] + (u16)party_id + sum_w);
+                C[k] = C[k] % P;
+                W[k] = (u16)(X[k] + (u16)party_id * R[k] + (P - 2) * R[k] * X[k]);
+                W[k] = W[k] % P;
+                sum_w = (u16)(sum_w + W[k]);
+            } else {
+                C[k] = (u16)((u64)(P - 1) * party_id * T[k] + X[k] + (u16)party_id + sum_w);
+                C[k] = C[k] % P;
+                W[k] = (u16)(X[k] + (u16)party_id * T[k] + (P - 2) * T[k] * X[k]);
+                W[k] = W[k] % P;
+                sum_w = (u16)(sum_w + W[k]);
+            }
+        }
+        for (int k = 0; k < 64; k++) {
+            u16 d = (u16)(S[k] * C[k]);
+            d_out[64 * i + k] = d % P;
+        }
+    }
+    return 0;
+}
+// privateCompare, party 2 (:402-426) is orc_snn_pc_helper.
+
+// msb, party 2 before round 1 (:473-508): x = buf_0[k] % L_1 +L buf_1[k] % L_1; lsb shares as XOR bytes out of
+// boolbufS[k]; Z_67 shares of the bits of x with share 0 = (u16)bufS[64 k + l] % 67.  Message to party j = xlsb_j | xbits_j.
+int orc_my_msb_helper_deal(u64 seed0, u64 seed1, u64 seedS, u64 i0, u64 n, i8 *xlsb0, u16 *xbits0, i8 *xlsb1, u16 *xbits1) {
+    std::vector<i64> w0(n), w1(n), dummy(n);
+    orc_prg_fill_buff(seed0, 0, i0, n, w0.data(), nullptr);
+    orc_prg_fill_buff(seed1, 0, i0, n, w1.data(), nullptr);
+    orc_prg_fill_buff(seedS, 0, i0, n, dummy.data(), xlsb0);
+    BuffReader rb(seedS, 64 * i0);
+    for (u64 k = 0; k < n; k++) {
+        const u64 x = add_L_1((u64)w0[k] % L_1, (u64)w1[k] % L_1);
+        xlsb1[k] = (i8)((i8)(x & 1) ^ xlsb0[k]);
+        for (int l = 0; l < 64; l++) {
+            u16 s = (u16)rb.next_int();
+            s = s % P;
+            xbits0[64 * k + l] = s;
+            xbits1[64 * k + l] = (u16)((u16)((x >> l) & 1) + P - s) % P;
+        }
+    }
+    return 0;
+}
+// party 2 after round 2 (:512-525): XOR shares of beta' with share 0 = boolbufS[n + k]
+int orc_my_msb_helper_beta(const i8 *beta1_plain, u64 n_total, u64 i0, u64 n, u64 seedS, i8 *b0, i8 *b1) {
+    std::vector<i64> dummy(n);
+    orc_prg_fill_buff(seedS, 0, n_total + i0, n, dummy.data(), b0);
+    for (u64 k = 0; k < n; k++) b1[k] = (i8)(beta1_plain[k] ^ b0[k]);
+    return 0;
+}
+// party 0/1 before round 1 (:446-452, :539-549): d = 2a, y = d +L d, x_j = buf2[k] % L_1, r_j = x_j +L y
+int orc_my_msb_party_open(const i64 *A, u64 seed2, u64 i0, u64 n, i64 *r_out) {
+    std::vector<i64> w(n);
+    orc_prg_fill_buff(seed2, 0, i0, n, w.data(), nullptr);
+    for (u64 k = 0; k < n; k++) {
+        const u64 d = 2 * (u64)A[k];
+        const u64 y = add_L_1(d, d);
+        r_out[k] = (i64)add_L_1((u64)w[k] % L_1, y);
+    }
+    return 0;
+}
+// plaintext privateCompare inputs of round 2 (:542-544, :554-559): beta = boolbuf01[k], R = r_peer +L r_own
+int orc_my_msb_party_pc_inputs(const i64 *r_own, const i64 *r_peer, u64 i0, u64 n, u64 seed01, i8 *beta_out, i64 *R_out) {
+    std::vector<i64> dummy(n);
+    orc_prg_fill_buff(seed01, 0, i0, n, dummy.data(), beta_out);
+    for (u64 k = 0; k < n; k++) R_out[k] = (i64)add_L_1((u64)r_peer[k], (u64)r_own[k]);
+    return 0;
+}
+// after round 3 (:573-581): XOR share of msb
+int orc_my_msb_party_finish(int party, const i8 *beta1_j, const i8 *beta0, const i8 *xlsb_j, const i64 *R, u64 n, i8 *B) {
+    for (u64 k = 0; k < n; k++) {
+        const i8 b = party == 0 ? beta1_j[k] : (i8)(beta1_j[k] ^ beta0[k]);
+        const i8 r0 = (i8)((u64)R[k] % 2);
+        B[k] = party == 1 ? (i8)(b ^ xlsb_j[k]) : (i8)(b ^ xlsb_j[k] ^ r0);
+    }
+    return 0;
+}
+// bit_inject, party 2 (:703-750): b = boolbuf_0 ^ boolbuf_1, u = buf_0 + buf_1 (index k); shares of b*u, (1^b)*u,
+// b_0*b_1 and b_0*(1^b_1) with share 0 = bufS[k], bufS[n+k], bufS[2n+k], bufS[3n+k].  Message to party j = V_j|W_j|S_j|T_j.
+int orc_my_bit_inject_dealer(u64 seed0, u64 seed1, u64 seedS, u64 n_total, u64 i0, u64 n, i64 *V0, i64 *W0, i64 *S0,
+                             i64 *T0, i64 *V1, i64 *W1, i64 *S1, i64 *T1) {
+    std::vector<i64> U0(n), U1(n);
+    std::vector<i8> B0(n), B1(n);
+    orc_prg_fill_buff(seed0, 0, i0, n, U0.data(), B0.data());
+    orc_prg_fill_buff(seed1, 0, i0, n, U1.data(), B1.data());
+    orc_prg_fill_buff(seedS, 0, i0, n, V0, nullptr);
+    orc_prg_fill_buff(seedS, 0, n_total + i0, n, W0, nullptr);
+    orc_prg_fill_buff(seedS, 0, 2 * n_total + i0, n, S0, nullptr);
+    orc_prg_fill_buff(seedS, 0, 3 * n_total + i0, n, T0, nullptr);
+    for (u64 i = 0; i < n; i++) {
+        const i8 b = (i8)(B0[i] ^ B1[i]);
+        const u64 u = (u64)U0[i] + (u64)U1[i];
+        V1[i] = (i64)((u64)(i64)b * u - (u64)V0[i]);
+        W1[i] = (i64)((u64)(i64)(1 ^ b) * u - (u64)W0[i]);
+        S1[i] = (i64)((u64)(i64)(B0[i] * B1[i]) - (u64)S0[i]);
+        T1[i] = (i64)((u64)(i64)(B0[i] * (1 ^ B1[i])) - (u64)T0[i]);
+    }
+    return 0;
+}
+// party 0/1 before the round (:606-623): y_j = x_j - buf2[k], c_j = boolbuf2[k] ^ a_j; message to the peer = y_j | c_j
+int orc_my_bit_inject_party_pre(const i64 *X, const i8 *A, u64 seed2, u64 i0, u64 n, i64 *y_out, i8 *c_out) {
+    std::vector<i64> U(n);
+    std::vector<i8> B(n);
+    orc_prg_fill_buff(seed2, 0, i0, n, U.data(), B.data());
+    for (u64 i = 0; i < n; i++) {
+        y_out[i] = (i64)((u64)X[i] - (u64)U[i]);
+        c_out[i] = (i8)(B[i] ^ A[i]);
+    }
+    return 0;
+}
+// party 0/1 after the round (:626-660)
+int orc_my_bit_inject_party_post(int party, u64 seed2, u64 i0, u64 n, const i64 *y_own, const i8 *c_own, const i64 *y_peer,
+                                 const i8 *c_peer, const i64 *V, const i64 *W, const i64 *S, const i64 *T, i64 *Z) {
+    std::vector<i64> U(n);
+    std::vector<i8> B(n);
+    orc_prg_fill_buff(seed2, 0, i0, n, U.data(), B.data());
+    for (u64 i = 0; i < n; i++) {
+        const u64 y = (u64)y_peer[i] + (u64)y_own[i];
+        const i8 cp = (i8)(c_peer[i] ^ c_own[i]);
+        if (cp == 0)
+            Z[i] = (i64)((u64)V[i] + y * ((u64)(i64)B[i] - 2 * (u64)S[i]));
+        else
+            Z[i] = (i64)((u64)W[i] + y * (((u64)party ^ (u64)(i64)B[i]) - 2 * (u64)T[i]));
+    }
+    return 0;
+}
+// reveal_vec_bools (:777-807): XOR of the two byte shares
+int orc_xor_bools(const i8 *a, const i8 *b, i8 *out, u64 n) {
+    for (u64 i = 0; i < n; i++) out[i] = (i8)(a[i] ^ b[i]);
+    return 0;
+}
+
 } // extern "C"
