@@ -16,6 +16,7 @@
 #include <thread>
 
 #include "../mpc_engine/ABY3Engine.hpp"
+#include "../mpc_engine/MyEngine.hpp"
 #include "../mpc_engine/SecurennEngine.hpp"
 #include "../utils/InProcMessenger.hpp"
 #include "../utils/SocketMessenger.hpp"
@@ -166,6 +167,62 @@ static void bench_securenn(VirtuleMessenger *messenger, size_t party, const Opti
     report(party, "bench_securenn msb & vector_mul", spent / opt.repeat, (double)vec_size, "elem");
 }
 
+static void bench_me(VirtuleMessenger *messenger, size_t party, const Options &opt) {
+    MyEngine engine(messenger, party);
+    PRgenerator rnd(0x5EED + 2, 0);
+    const size_t w = opt.width, vec_size = opt.vec ? opt.vec : w * 10;
+    double spent = 0;
+    for (size_t t = 0; t <= opt.repeat; t++) {
+        MatrixXl X(w, w), Y(w, w), Xj, Yj, Zj;
+        for (size_t i = 0; i < w; i++)
+            for (size_t k = 0; k < w; k++) {
+                X(i, k) = rnd.pop_int64() >> 48;
+                Y(i, k) = rnd.pop_int64() >> 48;
+            }
+        engine.share_matrix(X, Xj);
+        engine.share_matrix(Y, Yj);
+        auto t0 = Clock::now();
+        engine.matrix_mul(Xj, Yj, Zj);
+        for (size_t i = 0; i < w; i++)
+            for (size_t j = 0; j < w; j++) Zj(i, j) = Zj(i, j) >> 16; // benchmark/benchmark1.cpp:168-174
+        const double ms = ms_since(t0);
+        if (t) spent += ms;
+        if (t == opt.repeat) {
+            MatrixXl Z, Wp = X * Y;
+            engine.reveal_matrix(Zj, Z);
+            size_t bad = 0;
+            if (party != 2)
+                for (size_t i = 0; i < w; i++)
+                    for (size_t j = 0; j < w; j++) {
+                        const int64_t d = Z(i, j) - (Wp(i, j) >> 16);
+                        bad += !(d >= -1 && d <= 1);
+                    }
+            CHECK(bad == 0);
+        }
+    }
+    report(party, "bench_me matrix_mul & trunction", spent / opt.repeat, 3.0 * 2 * w * w * w, "ring op");
+
+    spent = 0;
+    for (size_t t = 0; t <= opt.repeat; t++) {
+        VecI64 X(vec_size), Xj, Zj, Z;
+        vecbool Aj;
+        for (size_t i = 0; i < vec_size; i++) X[i] = rnd.pop_int64() / 2;
+        engine.share(X, Xj);
+        auto t0 = Clock::now();
+        engine.msb(Xj, Aj);
+        engine.bit_inject(Xj, Aj, Zj);
+        const double ms = ms_since(t0);
+        if (t) spent += ms;
+        if (t == opt.repeat) {
+            engine.reveal(Zj, Z);
+            size_t bad = 0;
+            for (size_t i = 0; i < vec_size; i++) bad += Z[i] != (X[i] < 0 ? X[i] : 0);
+            CHECK(bad == 0);
+        }
+    }
+    report(party, "bench_me msb & bit_inject", spent / opt.repeat, (double)vec_size, "elem");
+}
+
 // One dense layer on additive shares: Z = X * W, rescaled by a local >> 16 on each share, then (optionally)
 // ReLU(a) = a - a * msb(a), as the reference benchmark composes it (benchmark/benchmark1.cpp:104-136).
 static void snn_dense(SecurennEngine &engine, const MatrixXl &Xj, const MatrixXl &Wj, bool relu, MatrixXl &out) {
@@ -255,6 +312,7 @@ static void bench_mlp(VirtuleMessenger *messenger, size_t party, const Options &
 static void party_main(VirtuleMessenger *messenger, size_t party, const Options &opt) {
     bench_aby3(messenger, party, opt);
     bench_securenn(messenger, party, opt);
+    bench_me(messenger, party, opt);
     if (opt.mlp) bench_mlp(messenger, party, opt);
 }
 

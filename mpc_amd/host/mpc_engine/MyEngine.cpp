@@ -1,0 +1,371 @@
+#include "MyEngine.hpp"
+
+#include "gpu_support.hpp"
+
+using mpcgpu::Dev;
+using mpcgpu::upload_string;
+
+namespace {
+const size_t W = sizeof(int64_t);
+const size_t ZP = sizeof(zpshare); // 128 bytes per element
+} // namespace
+
+MyEngine::MyEngine(VirtuleMessenger *_messenger, size_t _party_id) : messenger(_messenger), party_id(_party_id) {
+    message_send.resize(3);
+    message_recv.resize(3);
+    // prgs[k] is the stream shared with party k; prgs[party_id] is the private one (MyEngine.cpp:9-28)
+    static const uint64_t pair_key[3][3] = {{KEY0, KEY01, KEY20}, {KEY01, KEY1, KEY12}, {KEY20, KEY12, KEY2}};
+    assert(party_id < 3);
+    for (size_t k = 0; k < 3; k++) prgs.push_back(PRgenerator(pair_key[party_id][k], 0));
+    gpu = mpcgpu::open_context();
+}
+
+MyEngine::~MyEngine() { mpcx_shutdown(gpu); }
+
+// ---- additive sharing between parties 0 and 1 out of their common stream; no communication
+void MyEngine::share(const VecI64 &X_plain, VecI64 &Xj) {
+    const size_t n = X_plain.size();
+    Xj.resize(n);
+    for (size_t i = 0; i < n; i++) Xj[i] = 0;
+    if (party_id == 2 || n == 0) return;
+    PRgenerator &g = prgs[1 - party_id];
+    Dev<int64_t> x(gpu, X_plain.data(), n), out(gpu, n);
+    GPU_OK(gpu, mpcx_snn_share_local(gpu, (int)party_id, x, n, g.init_seed, g.pops, out));
+    g.advance(gpu, n);
+    out.down(Xj.data(), n);
+}
+
+void MyEngine::share_matrix(const MatrixXl &X_plain, MatrixXl &Xj) {
+    const size_t rows = X_plain.rows(), cols = X_plain.cols(), n = rows * cols;
+    Xj.resize(rows, cols);
+    for (size_t i = 0; i < n; i++) Xj.data()[i] = 0;
+    if (party_id == 2 || n == 0) return;
+    PRgenerator &g = prgs[1 - party_id];
+    // the words are popped in row-major element order (:81-87); Eigen stores column-major
+    Dev<int64_t> xc(gpu, X_plain.data(), n), xr(gpu, n), out(gpu, n), outc(gpu, n);
+    GPU_OK(gpu, mpcx_relayout(gpu, xc, xr, rows, cols, 1, 0));
+    GPU_OK(gpu, mpcx_snn_share_local(gpu, (int)party_id, xr, n, g.init_seed, g.pops, out));
+    g.advance(gpu, n);
+    GPU_OK(gpu, mpcx_relayout(gpu, out, outc, rows, cols, 0, 1));
+    outc.down(Xj.data(), n);
+}
+
+// ---- openings: parties 0 and 1 swap shares and copy them to party 2
+void MyEngine::reveal(const VecI64 &Xj, VecI64 &X_plain) {
+    const size_t n = Xj.size();
+    X_plain.resize(n);
+    if (party_id == 2) {
+        message_send[0].clear();
+        message_send[1].clear();
+    } else {
+        vecI642string(Xj, message_send[1 - party_id]);
+        message_send[2] = message_send[1 - party_id];
+    }
+    messenger->send_and_recv(message_send, message_recv);
+    Dev<int64_t> u(gpu, n), v(gpu, n), out(gpu, n);
+    if (party_id == 2) {
+        assert(message_recv[0].size() == n * W && message_recv[1].size() == n * W);
+        upload_string(u, message_recv[0]);
+        upload_string(v, message_recv[1]);
+    } else {
+        assert(message_recv[1 - party_id].size() == n * W);
+        upload_string(u, message_recv[1 - party_id]);
+        v.up(Xj.data(), n);
+    }
+    GPU_OK(gpu, mpcx_ring_add(gpu, u, v, out, n));
+    out.down(X_plain.data(), n);
+}
+
+void MyEngine::reveal_matrix(const MatrixXl &Xj, MatrixXl &X_plain) {
+    const size_t rows = Xj.rows(), cols = Xj.cols(), n = rows * cols;
+    X_plain.resize(rows, cols);
+    string own;
+    if (party_id == 2) {
+        message_send[0].clear();
+        message_send[1].clear();
+    } else {
+        matrix2string(Xj, own);
+        message_send[1 - party_id] = own;
+        message_send[2] = own;
+    }
+    messenger->send_and_recv(message_send, message_recv);
+    const string &u_s = party_id == 2 ? message_recv[0] : message_recv[1 - party_id];
+    const string &v_s = party_id == 2 ? message_recv[1] : own;
+    assert(u_s.size() == n * W && v_s.size() == n * W);
+    Dev<int64_t> u(gpu, n), v(gpu, n), out(gpu, n);
+    upload_string(u, u_s);
+    upload_string(v, v_s);
+    GPU_OK(gpu, mpcx_ring_add(gpu, u, v, out, n));
+    string res;
+    out.to_string(res);
+    string2matrix(res, X_plain);
+}
+
+void MyEngine::reveal_vec_bools(const vecbool &Xj, vecbool &X_plain) {
+    const size_t n = Xj.size();
+    X_plain.resize(n);
+    if (party_id == 2) {
+        message_send[0].clear();
+        message_send[1].clear();
+    } else {
+        vecbool2string(Xj, message_send[1 - party_id]);
+        message_send[2] = message_send[1 - party_id];
+    }
+    messenger->send_and_recv(message_send, message_recv);
+    Dev<int8_t> u(gpu, n), v(gpu, n), out(gpu, n);
+    if (party_id == 2) {
+        assert(message_recv[0].size() == n && message_recv[1].size() == n);
+        upload_string(u, message_recv[0]);
+        upload_string(v, message_recv[1]);
+    } else {
+        assert(message_recv[1 - party_id].size() == n);
+        upload_string(u, message_recv[1 - party_id]);
+        v.up(Xj.data(), n);
+    }
+    GPU_OK(gpu, mpcx_xor_bools(gpu, u, v, out, n));
+    out.down(X_plain.data(), n);
+}
+
+void MyEngine::reveal_L_1(const VecI64 &Xj, VecI64 &X_plain) {
+    const size_t n = Xj.size();
+    X_plain.resize(n);
+    if (party_id == 2) {
+        message_send[0].clear();
+        message_send[1].clear();
+    } else {
+        vecI642string(Xj, message_send[1 - party_id]);
+        message_send[2] = message_send[1 - party_id];
+    }
+    messenger->send_and_recv(message_send, message_recv);
+    Dev<int64_t> u(gpu, n), v(gpu, n), out(gpu, n);
+    if (party_id == 2) {
+        assert(message_recv[0].size() == n * W && message_recv[1].size() == n * W);
+        upload_string(u, message_recv[0]);
+        upload_string(v, message_recv[1]);
+    } else {
+        assert(message_recv[1 - party_id].size() == n * W);
+        upload_string(u, message_recv[1 - party_id]);
+        v.up(Xj.data(), n);
+    }
+    GPU_OK(gpu, mpcx_snn_add_L1(gpu, v, u, out, n));
+    out.down(X_plain.data(), n);
+}
+
+void MyEngine::reveal_zp(const vector<zpshare> &Xbits_j, vector<zpshare> &Xbits_plain) {
+    const size_t n = Xbits_j.size();
+    Xbits_plain.resize(n);
+    if (party_id == 2) {
+        message_send[0].clear();
+        message_send[1].clear();
+    } else {
+        vecZpshare2string(Xbits_j, message_send[1 - party_id]);
+        message_send[2] = message_send[1 - party_id];
+    }
+    messenger->send_and_recv(message_send, message_recv);
+    Dev<uint16_t> u(gpu, 64 * n), v(gpu, 64 * n), out(gpu, 64 * n);
+    if (party_id == 2) {
+        assert(message_recv[0].size() == n * ZP && message_recv[1].size() == n * ZP);
+        upload_string(u, message_recv[0]);
+        upload_string(v, message_recv[1]);
+    } else {
+        assert(message_recv[1 - party_id].size() == n * ZP);
+        upload_string(u, message_recv[1 - party_id]);
+        v.up(Xbits_j.data(), 64 * n);
+    }
+    GPU_OK(gpu, mpcx_snn_add_zp(gpu, u, v, out, 64 * n));
+    out.down(Xbits_plain.data(), 64 * n);
+}
+
+// ---- Beaver products, one round: party 2 sends C_j, parties 0/1 swap E_j | F_j in the same round
+void MyEngine::matrix_mul(const MatrixXl &Xj, const MatrixXl &Yj, MatrixXl &Zj) {
+    const size_t rows = Xj.rows(), lens = Xj.cols(), cols = Yj.cols();
+    assert(Yj.rows() == lens);
+    const size_t na = rows * lens, nb = lens * cols, nc = rows * cols;
+    Zj.resize(rows, cols);
+    if (party_id == 2) {
+        Dev<int64_t> c0(gpu, nc), c1(gpu, nc);
+        GPU_OK(gpu, mpcx_my_beaver_dealer_matmul(gpu, prgs[0].init_seed, prgs[1].init_seed, prgs[2].init_seed, rows, lens,
+                                                 cols, c0, c1));
+        c0.to_string(message_send[0]);
+        c1.to_string(message_send[1]);
+        messenger->send_and_recv(message_send, message_recv);
+        return;
+    }
+    const size_t peer = 1 - party_id;
+    const uint64_t s2 = prgs[2].init_seed;
+    Dev<int64_t> ef(gpu, na + nb), ef_peer(gpu, na + nb), c(gpu, nc), z(gpu, nc);
+    {
+        Dev<int64_t> x(gpu, Xj.data(), na), y(gpu, Yj.data(), nb);
+        GPU_OK(gpu, mpcx_my_beaver_party_open_matmul(gpu, x, y, 1, s2, rows, lens, cols, ef));
+    }
+    ef.to_string(message_send[peer]);
+    message_send[2].clear();
+    messenger->send_and_recv(message_send, message_recv);
+    assert(message_recv[2].size() == nc * W && message_recv[peer].size() == (na + nb) * W);
+    upload_string(c, message_recv[2]);
+    upload_string(ef_peer, message_recv[peer]);
+    GPU_OK(gpu, mpcx_my_beaver_party_finish_matmul(gpu, (int)party_id, s2, c, ef, ef_peer, rows, lens, cols, 1, z));
+    z.down(Zj.data(), nc);
+}
+
+void MyEngine::vector_mul(const VecI64 &Xj, const VecI64 &Yj, VecI64 &Zj) {
+    const size_t n = Xj.size();
+    assert((size_t)Yj.size() == n);
+    Zj.resize(n);
+    if (party_id == 2) {
+        Dev<int64_t> c0(gpu, n), c1(gpu, n);
+        GPU_OK(gpu, mpcx_my_beaver_dealer_vecmul(gpu, prgs[0].init_seed, prgs[1].init_seed, prgs[2].init_seed, n, 0, n, c0,
+                                                 c1));
+        c0.to_string(message_send[0]);
+        c1.to_string(message_send[1]);
+        messenger->send_and_recv(message_send, message_recv);
+        return;
+    }
+    const size_t peer = 1 - party_id;
+    const uint64_t s2 = prgs[2].init_seed;
+    Dev<int64_t> ef(gpu, 2 * n), ef_peer(gpu, 2 * n), c(gpu, n), z(gpu, n);
+    {
+        Dev<int64_t> x(gpu, Xj.data(), n), y(gpu, Yj.data(), n);
+        GPU_OK(gpu, mpcx_my_beaver_party_open_vecmul(gpu, x, y, s2, n, 0, n, ef));
+    }
+    ef.to_string(message_send[peer]);
+    message_send[2].clear();
+    messenger->send_and_recv(message_send, message_recv);
+    assert(message_recv[2].size() == n * W && message_recv[peer].size() == 2 * n * W);
+    upload_string(c, message_recv[2]);
+    upload_string(ef_peer, message_recv[peer]);
+    GPU_OK(gpu, mpcx_my_beaver_party_finish_vecmul(gpu, (int)party_id, s2, c, ef, ef_peer, n, 0, n, z));
+    z.down(Zj.data(), n);
+}
+
+// ---- privateCompare: parties 0/1 send masked difference digits to party 2, which learns beta' = beta xor (x > r)
+void MyEngine::privateCompare(const vector<zpshare> &Xbits_j, const vecbool &Beta1_plain, const VecI64 &R_palin,
+                              vecbool &Beta2_plain) {
+    const size_t n = Xbits_j.size();
+    assert(Beta1_plain.size() == n && (size_t)R_palin.size() == n);
+    Beta2_plain.resize(n);
+    if (party_id != 2) {
+        Dev<uint16_t> xb(gpu, (const uint16_t *)Xbits_j.data(), 64 * n), d(gpu, 64 * n);
+        Dev<int8_t> beta(gpu, Beta1_plain.data(), n);
+        Dev<int64_t> r(gpu, R_palin.data(), n);
+        GPU_OK(gpu, mpcx_my_pc_party(gpu, (int)party_id, xb, beta, r, 0, n, prgs[1 - party_id].init_seed, d));
+        message_send[1 - party_id].clear();
+        d.to_string(message_send[2]);
+        messenger->send_and_recv(message_send, message_recv);
+        return;
+    }
+    message_send[0].clear();
+    message_send[1].clear();
+    messenger->send_and_recv(message_send, message_recv);
+    assert(message_recv[0].size() == n * ZP && message_recv[1].size() == n * ZP);
+    Dev<uint16_t> d0(gpu, 64 * n), d1(gpu, 64 * n);
+    Dev<int8_t> b(gpu, n);
+    upload_string(d0, message_recv[0]);
+    upload_string(d1, message_recv[1]);
+    GPU_OK(gpu, mpcx_snn_pc_helper(gpu, d0, d1, n, b));
+    b.down(Beta2_plain.data(), n);
+}
+
+// ---- msb of a in [-2^62, 2^62): three rounds, XOR-shared result
+void MyEngine::msb(const VecI64 &Aj, vecbool &Bj) {
+    const size_t n = Aj.size();
+    Bj.assign(n, 0);
+    if (party_id == 2) {
+        const uint64_t s0 = prgs[0].init_seed, s1 = prgs[1].init_seed, sS = prgs[2].init_seed;
+        {
+            Dev<int8_t> l0(gpu, n), l1(gpu, n);
+            Dev<uint16_t> xb0(gpu, 64 * n), xb1(gpu, 64 * n);
+            GPU_OK(gpu, mpcx_my_msb_helper_deal(gpu, s0, s1, sS, 0, n, l0, xb0, l1, xb1));
+            for (size_t j = 0; j < 2; j++) { // lsb share | bit shares (:502-508)
+                message_send[j].resize(n + n * ZP);
+                if (n) {
+                    (j ? l1 : l0).down(&message_send[j][0], n);
+                    (j ? xb1 : xb0).down(&message_send[j][n], 64 * n);
+                }
+            }
+        }
+        messenger->send_and_recv(message_send, message_recv); // round 1
+        message_send[0].clear();
+        message_send[1].clear();
+        messenger->send_and_recv(message_send, message_recv); // round 2: privateCompare as the helper
+        assert(message_recv[0].size() == n * ZP && message_recv[1].size() == n * ZP);
+        Dev<uint16_t> d0(gpu, 64 * n), d1(gpu, 64 * n);
+        Dev<int8_t> beta1(gpu, n), b0(gpu, n), b1(gpu, n);
+        upload_string(d0, message_recv[0]);
+        upload_string(d1, message_recv[1]);
+        GPU_OK(gpu, mpcx_snn_pc_helper(gpu, d0, d1, n, beta1));
+        GPU_OK(gpu, mpcx_my_msb_helper_beta(gpu, beta1, n, 0, n, sS, b0, b1));
+        b0.to_string(message_send[0]);
+        b1.to_string(message_send[1]);
+        messenger->send_and_recv(message_send, message_recv); // round 3
+        return;
+    }
+    const size_t peer = 1 - party_id;
+    const uint64_t s01 = prgs[peer].init_seed, s2 = prgs[2].init_seed;
+    Dev<int64_t> rj(gpu, n), rpeer(gpu, n), R(gpu, n);
+    {
+        Dev<int64_t> a(gpu, Aj.data(), n);
+        GPU_OK(gpu, mpcx_my_msb_party_open(gpu, a, s2, 0, n, rj));
+    }
+    message_send[2].clear();
+    rj.to_string(message_send[peer]);
+    messenger->send_and_recv(message_send, message_recv); // round 1
+    assert(message_recv[peer].size() == n * W && message_recv[2].size() == n + n * ZP);
+    upload_string(rpeer, message_recv[peer]);
+    Dev<int8_t> beta0(gpu, n), xlsb(gpu, n), beta1(gpu, n), out(gpu, n);
+    Dev<uint16_t> xbits(gpu, 64 * n), d(gpu, 64 * n);
+    upload_string(xlsb, message_recv[2], 0, n);
+    upload_string(xbits, message_recv[2], n, n * ZP);
+    GPU_OK(gpu, mpcx_my_msb_party_pc_inputs(gpu, rj, rpeer, 0, n, s01, beta0, R));
+    GPU_OK(gpu, mpcx_my_pc_party(gpu, (int)party_id, xbits, beta0, R, 0, n, s01, d));
+    message_send[peer].clear();
+    d.to_string(message_send[2]);
+    messenger->send_and_recv(message_send, message_recv); // round 2
+    message_send[2].clear();
+    message_send[peer].clear();
+    messenger->send_and_recv(message_send, message_recv); // round 3: share of beta'
+    assert(message_recv[2].size() == n);
+    upload_string(beta1, message_recv[2]);
+    GPU_OK(gpu, mpcx_my_msb_party_finish(gpu, (int)party_id, beta1, beta0, xlsb, R, n, out));
+    out.down(Bj.data(), n);
+}
+
+// ---- x * a for an XOR-shared boolean a, one round
+void MyEngine::bit_inject(const VecI64 &Xj, const vecbool &Aj, VecI64 &Zj) {
+    const size_t n = Xj.size();
+    assert(Aj.size() == n);
+    Zj.resize(n);
+    if (party_id == 2) {
+        Dev<int64_t> m0(gpu, 4 * n), m1(gpu, 4 * n); // V | W | S | T
+        GPU_OK(gpu, mpcx_my_bit_inject_dealer(gpu, prgs[0].init_seed, prgs[1].init_seed, prgs[2].init_seed, n, 0, n, m0.p,
+                                              m0.p + n, m0.p + 2 * n, m0.p + 3 * n, m1.p, m1.p + n, m1.p + 2 * n,
+                                              m1.p + 3 * n));
+        m0.to_string(message_send[0]);
+        m1.to_string(message_send[1]);
+        messenger->send_and_recv(message_send, message_recv);
+        return;
+    }
+    const size_t peer = 1 - party_id;
+    const uint64_t s2 = prgs[2].init_seed;
+    Dev<int64_t> y(gpu, n), ypeer(gpu, n), deal(gpu, 4 * n), z(gpu, n);
+    Dev<int8_t> c(gpu, n), cpeer(gpu, n);
+    {
+        Dev<int64_t> x(gpu, Xj.data(), n);
+        Dev<int8_t> a(gpu, Aj.data(), n);
+        GPU_OK(gpu, mpcx_my_bit_inject_party_pre(gpu, x, a, s2, 0, n, y, c));
+    }
+    message_send[peer].resize(n * W + n); // y | c (:621-623)
+    if (n) {
+        y.down(&message_send[peer][0], n);
+        c.down(&message_send[peer][n * W], n);
+    }
+    message_send[2].clear();
+    messenger->send_and_recv(message_send, message_recv);
+    assert(message_recv[peer].size() == n * W + n && message_recv[2].size() == 4 * n * W);
+    upload_string(ypeer, message_recv[peer], 0, n * W);
+    upload_string(cpeer, message_recv[peer], n * W, n);
+    upload_string(deal, message_recv[2]);
+    GPU_OK(gpu, mpcx_my_bit_inject_party_post(gpu, (int)party_id, s2, 0, n, y, c, ypeer, cpeer, deal.p, deal.p + n,
+                                              deal.p + 2 * n, deal.p + 3 * n, z));
+    z.down(Zj.data(), n);
+}

@@ -9,6 +9,7 @@
 #include <thread>
 
 #include "../mpc_engine/ABY3Engine.hpp"
+#include "../mpc_engine/MyEngine.hpp"
 #include "../mpc_engine/SecurennEngine.hpp"
 #include "../utils/InProcMessenger.hpp"
 #include "../utils/util.hpp"
@@ -261,6 +262,82 @@ static void snn_party(InProcHub *hub, size_t p) {
     }
 }
 
+// the checks of test/test_Myengine.cpp, plus the benchmark's size (n = 2000, beyond BUFF_NUM for privateCompare)
+static void my_party(InProcHub *hub, size_t p) {
+    InProcMessenger msgr(hub, p);
+    MyEngine e(&msgr, p);
+    PRgenerator g(55, 0);
+    {
+        const size_t n = 10;
+        VecI64 X(n), Y(n), Xj, Yj, Zj, Xr, Z;
+        for (size_t i = 0; i < n; i++) {
+            X[i] = g.pop_int64();
+            Y[i] = g.pop_int64();
+        }
+        e.share(X, Xj);
+        e.share(Y, Yj);
+        e.reveal(Xj, Xr);
+        CHECK(Xr == X);
+        e.vector_mul(Xj, Yj, Zj);
+        e.reveal(Zj, Z);
+        CHECK(Z == X * Y);
+        const size_t rows = 9, lens = 11, cols = 10;
+        MatrixXl Mx(rows, lens), My(lens, cols), Mxj, Myj, Mzj, Mr, Mz;
+        for (size_t i = 0; i < rows; i++)
+            for (size_t k = 0; k < lens; k++) Mx(i, k) = g.pop_int64();
+        for (size_t i = 0; i < lens; i++)
+            for (size_t k = 0; k < cols; k++) My(i, k) = g.pop_int64();
+        e.share_matrix(Mx, Mxj);
+        e.share_matrix(My, Myj);
+        e.reveal_matrix(Mxj, Mr);
+        CHECK(Mr == Mx);
+        e.matrix_mul(Mxj, Myj, Mzj);
+        e.reveal_matrix(Mzj, Mz);
+        CHECK(Mz == Mx * My);
+    }
+    {
+        // privateCompare on the corner values of test/test_Myengine.cpp:101-109 (inputs in [0, 2^64 - 2])
+        const size_t n = 10;
+        VecI64 X(n), R(n);
+        for (size_t i = 0; i < n; i++) {
+            X[i] = (int64_t)((uint64_t)g.pop_int64() % L_1);
+            R[i] = (int64_t)((uint64_t)g.pop_int64() % L_1);
+        }
+        X[0] = 0, X[1] = -2, R[3] = 0, R[4] = -2, X[5] = R[5];
+        X[6] = (int64_t)(((uint64_t)R[6] + 1) % L_1);
+        X[7] = (int64_t)(((uint64_t)R[7] - 1) % L_1);
+        vector<zpshare> xs[2], plain(n);
+        xs[0].resize(n);
+        xs[1].resize(n);
+        vecbool B1(n), B2(n);
+        for (size_t i = 0; i < n; i++)
+            for (size_t k = 0; k < 64; k++) {
+                plain[i][k] = ((uint64_t)X[i] >> k) & 1;
+                xs[0][i][k] = (uint16_t)g.pop_int64() % P;
+                xs[1][i][k] = (uint16_t)(plain[i][k] + P - xs[0][i][k]) % P;
+            }
+        for (size_t i = 0; i < n; i++) B1[i] = g.pop_bool();
+        e.privateCompare(p == 2 ? plain : xs[p], B1, R, B2);
+        if (p == 2)
+            for (size_t i = 0; i < n; i++) CHECK(((uint64_t)X[i] > (uint64_t)R[i]) == (B1[i] ^ B2[i]));
+    }
+    for (size_t n : {(size_t)10, (size_t)2000}) {
+        VecI64 X(n), Xj, Zj, Z;
+        vecbool Aj, A;
+        for (size_t i = 0; i < n; i++) X[i] = g.pop_int64() / 2;
+        X[0] = 0, X[1] = -1, X[2] = -2, X[3] = (int64_t)-1 << 62, X[4] = ((int64_t)1 << 62) - 1;
+        e.share(X, Xj);
+        if (p != 2) Xj[2] = -1; // test/test_Myengine.cpp:170: both shares -1, the value stays -2
+        e.msb(Xj, Aj);
+        e.reveal_vec_bools(Aj, A);
+        for (size_t i = 0; i < n; i++) CHECK(A[i] == (X[i] < 0));
+        e.bit_inject(Xj, Aj, Zj);
+        e.reveal(Zj, Z);
+        for (size_t i = 0; i < n; i++) CHECK(Z[i] == X[i] * A[i]);
+        if (p != 2 && n == 2000) printf("KAT my_relu_2000_Z %zu %016lX\n", p, (unsigned long)fnv(Zj.data(), n));
+    }
+}
+
 template <class F> static void run3(F party) {
     InProcHub hub;
     std::thread t0(party, &hub, 0), t1(party, &hub, 1), t2(party, &hub, 2);
@@ -273,6 +350,7 @@ int main() {
     run3(aby3_kat_party);
     run3(aby3_party);
     run3(snn_party);
+    run3(my_party);
     if (failures.load()) {
         printf("host_selftest: %d check(s) FAILED\n", failures.load());
         return 1;
