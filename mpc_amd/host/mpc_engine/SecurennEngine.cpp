@@ -233,6 +233,182 @@ void SecurennEngine::reveal_zp(const vector<zpshare> &Xbits_j, vector<zpshare> &
     out.down(Xbits_plain.data(), 64 * n);
 }
 
+// The multi-round protocols below keep every intermediate value on the device: a message is downloaded once
+// into its send slot and a received message uploaded once; the public methods only move their arguments in and
+// their results out.  (`e` is the engine; these helpers are file-local so the class keeps the reference's surface.)
+namespace {
+
+// privateCompare, parties 0/1 (one round): d -> party 2
+void pc_party_dev(SecurennEngine &e, const Dev<uint16_t> &xbits, const Dev<int8_t> &beta, const Dev<int64_t> &r, size_t n) {
+    Dev<uint16_t> d(e.gpu, 64 * n);
+    GPU_OK(e.gpu, mpcx_snn_pc_party(e.gpu, (int)e.party_id, xbits, beta, r, n, 0, n, e.prgs[1 - e.party_id].init_seed, d));
+    e.message_send[1 - e.party_id].clear();
+    d.to_string(e.message_send[2]);
+    e.messenger->send_and_recv(e.message_send, e.message_recv);
+}
+// privateCompare, party 2 (one round): beta' on the device
+void pc_helper_dev(SecurennEngine &e, size_t n, Dev<int8_t> &beta2) {
+    e.message_send[0].clear();
+    e.message_send[1].clear();
+    e.messenger->send_and_recv(e.message_send, e.message_recv);
+    assert(e.message_recv[0].size() == n * ZP && e.message_recv[1].size() == n * ZP);
+    Dev<uint16_t> d0(e.gpu, 64 * n), d1(e.gpu, 64 * n);
+    upload_string(d0, e.message_recv[0]);
+    upload_string(d1, e.message_recv[1]);
+    GPU_OK(e.gpu, mpcx_snn_pc_helper(e.gpu, d0, d1, n, beta2));
+}
+// vector_mul, party 2 (two rounds)
+void vecmul_dealer(SecurennEngine &e, size_t n) {
+    Dev<int64_t> t0(e.gpu, 3 * n), t1(e.gpu, 3 * n); // A_i | B_i | C_i
+    GPU_OK(e.gpu, mpcx_snn_beaver_dealer_vecmul(e.gpu, e.prgs[2].init_seed, n, 0, n, t0.p, t0.p + n, t0.p + 2 * n, t1.p,
+                                                t1.p + n, t1.p + 2 * n));
+    t0.to_string(e.message_send[0]);
+    t1.to_string(e.message_send[1]);
+    e.messenger->send_and_recv(e.message_send, e.message_recv); // round 1
+    e.message_send[0].clear();
+    e.message_send[1].clear();
+    e.messenger->send_and_recv(e.message_send, e.message_recv); // round 2
+}
+// vector_mul, parties 0/1 (two rounds): z = share of x * y
+void vecmul_party_dev(SecurennEngine &e, const Dev<int64_t> &x, const Dev<int64_t> &y, size_t n, Dev<int64_t> &z) {
+    const size_t peer = 1 - e.party_id;
+    for (auto &m : e.message_send) m.clear();
+    e.messenger->send_and_recv(e.message_send, e.message_recv); // round 1
+    assert(e.message_recv[2].size() == 3 * n * W);
+    Dev<int64_t> t(e.gpu, 3 * n), ef(e.gpu, 2 * n), efp(e.gpu, 2 * n);
+    upload_string(t, e.message_recv[2]);
+    GPU_OK(e.gpu, mpcx_snn_beaver_party_open_vecmul(e.gpu, x, y, t.p, t.p + n, n, ef.p, ef.p + n));
+    ef.to_string(e.message_send[peer]);
+    e.message_send[2].clear();
+    e.messenger->send_and_recv(e.message_send, e.message_recv); // round 2
+    assert(e.message_recv[peer].size() == 2 * n * W);
+    upload_string(efp, e.message_recv[peer]);
+    GPU_OK(e.gpu, mpcx_snn_beaver_party_finish_vecmul(e.gpu, (int)e.party_id, t.p, t.p + n, t.p + 2 * n, ef.p, ef.p + n,
+                                                      efp.p, efp.p + n, n, z));
+}
+
+// shareConvert (four rounds); parties 0/1: a -> y, party 2: no input, no output
+void share_convert_dev(SecurennEngine &e, const Dev<int64_t> *a, size_t n, Dev<int64_t> *y) {
+    mpcx_ctx *gpu = e.gpu;
+    if (e.party_id != 2) {
+        const size_t peer = 1 - e.party_id;
+        const uint64_t s01 = e.prgs[peer].init_seed;
+        Dev<int64_t> x(gpu, n);
+        GPU_OK(gpu, mpcx_snn_sc_party_open(gpu, (int)e.party_id, *a, n, 0, n, s01, x));
+        e.message_send[peer].clear();
+        x.to_string(e.message_send[2]);
+        e.messenger->send_and_recv(e.message_send, e.message_recv); // round 1
+        e.message_send[2].clear();
+        e.messenger->send_and_recv(e.message_send, e.message_recv); // round 2: x bits over Z_67 | delta_j
+        assert(e.message_recv[2].size() == n * (ZP + W));
+        Dev<uint16_t> xbits(gpu, 64 * n);
+        Dev<int64_t> delta(gpu, n), rm1(gpu, n), eta1(gpu, n);
+        Dev<int8_t> eta2(gpu, n);
+        upload_string(xbits, e.message_recv[2], 0, n * ZP);
+        upload_string(delta, e.message_recv[2], n * ZP, n * W);
+        GPU_OK(gpu, mpcx_snn_sc_party_pc_inputs(gpu, n, 0, n, s01, eta2, rm1));
+        pc_party_dev(e, xbits, eta2, rm1, n); // round 3
+        e.message_send[peer].clear();
+        e.message_send[2].clear();
+        e.messenger->send_and_recv(e.message_send, e.message_recv); // round 4: eta'_j
+        assert(e.message_recv[2].size() == n * W);
+        upload_string(eta1, e.message_recv[2]);
+        GPU_OK(gpu, mpcx_snn_sc_party_finish(gpu, (int)e.party_id, *a, delta, eta1, n, 0, n, s01, *y));
+        return;
+    }
+    const uint64_t sS = e.prgs[2].init_seed;
+    e.message_send[0].clear(); // nothing to say in round 1 (parties 0/1 ignore this slot)
+    e.message_send[1].clear();
+    e.messenger->send_and_recv(e.message_send, e.message_recv); // round 1
+    assert(e.message_recv[0].size() == n * W && e.message_recv[1].size() == n * W);
+    {
+        Dev<int64_t> x0(gpu, n), x1(gpu, n), d0(gpu, n), d1(gpu, n);
+        Dev<uint16_t> xb0(gpu, 64 * n), xb1(gpu, 64 * n);
+        upload_string(x0, e.message_recv[0]);
+        upload_string(x1, e.message_recv[1]);
+        GPU_OK(gpu, mpcx_snn_sc_helper_split(gpu, x0, x1, n, 0, n, sS, xb0, d0, xb1, d1));
+        for (size_t j = 0; j < 2; j++) { // bit shares | delta_j
+            e.message_send[j].resize(n * (ZP + W));
+            if (n) {
+                (j ? xb1 : xb0).down(&e.message_send[j][0], 64 * n);
+                (j ? d1 : d0).down(&e.message_send[j][n * ZP], n);
+            }
+        }
+    }
+    e.messenger->send_and_recv(e.message_send, e.message_recv); // round 2
+    Dev<int8_t> eta1_plain(gpu, n);
+    pc_helper_dev(e, n, eta1_plain); // round 3
+    Dev<int64_t> e0(gpu, n), e1(gpu, n);
+    GPU_OK(gpu, mpcx_snn_sc_helper_eta(gpu, eta1_plain, n, 0, n, sS, e0, e1));
+    e0.to_string(e.message_send[0]);
+    e1.to_string(e.message_send[1]);
+    e.messenger->send_and_recv(e.message_send, e.message_recv); // round 4
+}
+
+// msb over Z_{2^64-1} (= lsb of 2a), result shared over Z_2^64; six rounds
+void msb_L1_dev(SecurennEngine &e, const Dev<int64_t> *a, size_t n, Dev<int64_t> *b) {
+    mpcx_ctx *gpu = e.gpu;
+    if (e.party_id == 2) {
+        const uint64_t sS = e.prgs[2].init_seed;
+        {
+            Dev<int64_t> x0(gpu, n), l0(gpu, n), x1(gpu, n), l1(gpu, n);
+            Dev<uint16_t> xb0(gpu, 64 * n), xb1(gpu, 64 * n);
+            GPU_OK(gpu, mpcx_snn_msbl1_helper_deal(gpu, n, 0, n, sS, x0, l0, xb0, x1, l1, xb1));
+            for (size_t j = 0; j < 2; j++) { // x_j | lsb(x)_j | bits of x over Z_67
+                e.message_send[j].resize(n * (2 * W + ZP));
+                if (n) {
+                    (j ? x1 : x0).down(&e.message_send[j][0], n);
+                    (j ? l1 : l0).down(&e.message_send[j][n * W], n);
+                    (j ? xb1 : xb0).down(&e.message_send[j][2 * n * W], 64 * n);
+                }
+            }
+        }
+        e.messenger->send_and_recv(e.message_send, e.message_recv); // round 1
+        e.message_send[0].clear();
+        e.message_send[1].clear();
+        e.messenger->send_and_recv(e.message_send, e.message_recv); // round 2
+        Dev<int8_t> beta1_plain(gpu, n);
+        pc_helper_dev(e, n, beta1_plain); // round 3
+        Dev<int64_t> b0(gpu, n), b1(gpu, n);
+        GPU_OK(gpu, mpcx_snn_msbl1_helper_beta(gpu, beta1_plain, n, 0, n, sS, b0, b1));
+        b0.to_string(e.message_send[0]);
+        b1.to_string(e.message_send[1]);
+        e.messenger->send_and_recv(e.message_send, e.message_recv); // round 4
+        vecmul_dealer(e, n);                                        // rounds 5-6
+        return;
+    }
+    const size_t peer = 1 - e.party_id;
+    const uint64_t s01 = e.prgs[peer].init_seed;
+    e.message_send[2].clear();
+    e.message_send[peer].clear();
+    e.messenger->send_and_recv(e.message_send, e.message_recv); // round 1
+    assert(e.message_recv[2].size() == n * (2 * W + ZP));
+    Dev<int64_t> xj(gpu, n), xlsb(gpu, n), rj(gpu, n), rpeer(gpu, n), R(gpu, n);
+    Dev<uint16_t> xbits(gpu, 64 * n);
+    upload_string(xj, e.message_recv[2], 0, n * W);
+    upload_string(xlsb, e.message_recv[2], n * W, n * W);
+    upload_string(xbits, e.message_recv[2], 2 * n * W, n * ZP);
+    GPU_OK(gpu, mpcx_snn_msbl1_party_open(gpu, *a, xj, n, rj));
+    rj.to_string(e.message_send[peer]);
+    e.messenger->send_and_recv(e.message_send, e.message_recv); // round 2: open r = 2a + x
+    assert(e.message_recv[peer].size() == n * W);
+    upload_string(rpeer, e.message_recv[peer]);
+    Dev<int8_t> beta0(gpu, n);
+    GPU_OK(gpu, mpcx_snn_msbl1_party_pc_inputs(gpu, rj, rpeer, 0, n, s01, beta0, R));
+    pc_party_dev(e, xbits, beta0, R, n); // round 3
+    e.message_send[2].clear();
+    e.message_send[peer].clear();
+    e.messenger->send_and_recv(e.message_send, e.message_recv); // round 4: share of beta'
+    assert(e.message_recv[2].size() == n * W);
+    Dev<int64_t> beta1(gpu, n), gamma(gpu, n), delta(gpu, n), theta(gpu, n);
+    upload_string(beta1, e.message_recv[2]);
+    GPU_OK(gpu, mpcx_snn_msbl1_party_mid(gpu, (int)e.party_id, beta1, xlsb, beta0, R, n, gamma, delta));
+    vecmul_party_dev(e, gamma, delta, n, theta); // rounds 5-6
+    GPU_OK(gpu, mpcx_snn_msbl1_party_finish(gpu, gamma, delta, theta, n, *b));
+}
+
+} // namespace
+
 // ---- privateCompare: parties 0/1 send masked difference digits to party 2, which learns beta' = beta xor (x > r)
 void SecurennEngine::privateCompare(const vector<zpshare> &Xbits_j, const vector<int8_t> &Beta1_plain,
                                     const vector<int64_t> &R_palin, vector<int8_t> &Beta2_plain) {
@@ -240,24 +416,14 @@ void SecurennEngine::privateCompare(const vector<zpshare> &Xbits_j, const vector
     assert(Beta1_plain.size() == n && R_palin.size() == n);
     Beta2_plain.assign(n, 0);
     if (party_id != 2) {
-        Dev<uint16_t> xb(gpu, (const uint16_t *)Xbits_j.data(), 64 * n), d(gpu, 64 * n);
+        Dev<uint16_t> xb(gpu, (const uint16_t *)Xbits_j.data(), 64 * n);
         Dev<int8_t> beta(gpu, Beta1_plain.data(), n);
         Dev<int64_t> r(gpu, R_palin.data(), n);
-        GPU_OK(gpu, mpcx_snn_pc_party(gpu, (int)party_id, xb, beta, r, n, 0, n, prgs[1 - party_id].init_seed, d));
-        message_send[1 - party_id].clear();
-        d.to_string(message_send[2]);
-        messenger->send_and_recv(message_send, message_recv);
+        pc_party_dev(*this, xb, beta, r, n);
         return;
     }
-    message_send[0].clear();
-    message_send[1].clear();
-    messenger->send_and_recv(message_send, message_recv);
-    assert(message_recv[0].size() == n * ZP && message_recv[1].size() == n * ZP);
-    Dev<uint16_t> d0(gpu, 64 * n), d1(gpu, 64 * n);
     Dev<int8_t> b(gpu, n);
-    upload_string(d0, message_recv[0]);
-    upload_string(d1, message_recv[1]);
-    GPU_OK(gpu, mpcx_snn_pc_helper(gpu, d0, d1, n, b));
+    pc_helper_dev(*this, n, b);
     b.down(Beta2_plain.data(), n);
 }
 
@@ -265,166 +431,40 @@ void SecurennEngine::privateCompare(const vector<zpshare> &Xbits_j, const vector
 void SecurennEngine::shareConvert(const vector<int64_t> &Aj, vector<int64_t> &Yj) {
     const size_t n = Aj.size();
     Yj.assign(n, 0);
-    if (party_id != 2) {
-        const size_t peer = 1 - party_id;
-        const uint64_t s01 = prgs[peer].init_seed;
-        Dev<int64_t> a(gpu, Aj.data(), n), x(gpu, n);
-        GPU_OK(gpu, mpcx_snn_sc_party_open(gpu, (int)party_id, a, n, 0, n, s01, x));
-        message_send[peer].clear();
-        x.to_string(message_send[2]);
-        messenger->send_and_recv(message_send, message_recv); // round 1
-        message_send[2].clear();
-        messenger->send_and_recv(message_send, message_recv); // round 2: x bits over Z_67 | delta_j
-        assert(message_recv[2].size() == n * (ZP + W));
-        vector<zpshare> xbits;
-        string2vecZpshare(message_recv[2].substr(0, n * ZP), xbits);
-        Dev<int64_t> delta(gpu, n);
-        upload_string(delta, message_recv[2], n * ZP, n * W);
-        vector<int8_t> eta2(n), dummy;
-        vector<int64_t> rm1(n);
-        {
-            Dev<int8_t> e(gpu, n);
-            Dev<int64_t> r(gpu, n);
-            GPU_OK(gpu, mpcx_snn_sc_party_pc_inputs(gpu, n, 0, n, s01, e, r));
-            e.down(eta2.data(), n);
-            r.down(rm1.data(), n);
-        }
-        privateCompare(xbits, eta2, rm1, dummy); // round 3
-        message_send[peer].clear();
-        message_send[2].clear();
-        messenger->send_and_recv(message_send, message_recv); // round 4: eta'_j
-        assert(message_recv[2].size() == n * W);
-        Dev<int64_t> eta1(gpu, n), y(gpu, n);
-        upload_string(eta1, message_recv[2]);
-        GPU_OK(gpu, mpcx_snn_sc_party_finish(gpu, (int)party_id, a, delta, eta1, n, 0, n, s01, y));
-        y.down(Yj.data(), n);
+    if (party_id == 2) {
+        share_convert_dev(*this, nullptr, n, nullptr);
         return;
     }
-    const uint64_t sS = prgs[2].init_seed;
-    message_send[0].clear(); // nothing to say in round 1 (parties 0/1 ignore this slot)
-    message_send[1].clear();
-    messenger->send_and_recv(message_send, message_recv); // round 1
-    assert(message_recv[0].size() == n * W && message_recv[1].size() == n * W);
-    {
-        Dev<int64_t> x0(gpu, n), x1(gpu, n), d0(gpu, n), d1(gpu, n);
-        Dev<uint16_t> xb0(gpu, 64 * n), xb1(gpu, 64 * n);
-        upload_string(x0, message_recv[0]);
-        upload_string(x1, message_recv[1]);
-        GPU_OK(gpu, mpcx_snn_sc_helper_split(gpu, x0, x1, n, 0, n, sS, xb0, d0, xb1, d1));
-        string tmp;
-        xb0.to_string(message_send[0]);
-        d0.to_string(tmp);
-        append(message_send[0], tmp);
-        xb1.to_string(message_send[1]);
-        d1.to_string(tmp);
-        append(message_send[1], tmp);
-    }
-    messenger->send_and_recv(message_send, message_recv); // round 2
-    vector<zpshare> pad_bits(n);
-    vector<int8_t> pad_beta(n), eta1_plain;
-    vector<int64_t> pad_r(n);
-    privateCompare(pad_bits, pad_beta, pad_r, eta1_plain); // round 3
-    {
-        Dev<int8_t> e(gpu, eta1_plain.data(), n);
-        Dev<int64_t> e0(gpu, n), e1(gpu, n);
-        GPU_OK(gpu, mpcx_snn_sc_helper_eta(gpu, e, n, 0, n, sS, e0, e1));
-        e0.to_string(message_send[0]);
-        e1.to_string(message_send[1]);
-    }
-    messenger->send_and_recv(message_send, message_recv); // round 4
+    Dev<int64_t> a(gpu, Aj.data(), n), y(gpu, n);
+    share_convert_dev(*this, &a, n, &y);
+    y.down(Yj.data(), n);
 }
 
-// ---- msb over Z_{2^64-1} (= lsb of 2a), result shared over Z_2^64; six rounds
+// ---- msb over Z_{2^64-1}, six rounds
 void SecurennEngine::msb_L_1(const vector<int64_t> &Aj, vector<int64_t> &Bj) {
     const size_t n = Aj.size();
     Bj.assign(n, 0);
     if (party_id == 2) {
-        const uint64_t sS = prgs[2].init_seed;
-        {
-            Dev<int64_t> x0(gpu, n), l0(gpu, n), x1(gpu, n), l1(gpu, n);
-            Dev<uint16_t> xb0(gpu, 64 * n), xb1(gpu, 64 * n);
-            GPU_OK(gpu, mpcx_snn_msbl1_helper_deal(gpu, n, 0, n, sS, x0, l0, xb0, x1, l1, xb1));
-            string tmp;
-            x0.to_string(message_send[0]);
-            l0.to_string(tmp);
-            append(message_send[0], tmp);
-            xb0.to_string(tmp);
-            append(message_send[0], tmp);
-            x1.to_string(message_send[1]);
-            l1.to_string(tmp);
-            append(message_send[1], tmp);
-            xb1.to_string(tmp);
-            append(message_send[1], tmp);
-        }
-        messenger->send_and_recv(message_send, message_recv); // round 1
-        message_send[0].clear();
-        message_send[1].clear();
-        messenger->send_and_recv(message_send, message_recv); // round 2
-        vector<zpshare> pad_bits(n);
-        vector<int8_t> pad_beta(n), beta1_plain;
-        vector<int64_t> pad(n);
-        privateCompare(pad_bits, pad_beta, pad, beta1_plain); // round 3
-        {
-            Dev<int8_t> b(gpu, beta1_plain.data(), n);
-            Dev<int64_t> b0(gpu, n), b1(gpu, n);
-            GPU_OK(gpu, mpcx_snn_msbl1_helper_beta(gpu, b, n, 0, n, sS, b0, b1));
-            b0.to_string(message_send[0]);
-            b1.to_string(message_send[1]);
-        }
-        messenger->send_and_recv(message_send, message_recv); // round 4
-        vector<int64_t> out;
-        vector_mul(pad, pad, out); // rounds 5-6 as the dealer
+        msb_L1_dev(*this, nullptr, n, nullptr);
         return;
     }
-    const size_t peer = 1 - party_id;
-    const uint64_t s01 = prgs[peer].init_seed;
-    message_send[2].clear();
-    message_send[peer].clear();
-    messenger->send_and_recv(message_send, message_recv); // round 1: x_j | lsb(x)_j | bits of x over Z_67
-    assert(message_recv[2].size() == n * (2 * W + ZP));
-    Dev<int64_t> a(gpu, Aj.data(), n), xj(gpu, n), xlsb(gpu, n), rj(gpu, n), rpeer(gpu, n);
-    upload_string(xj, message_recv[2], 0, n * W);
-    upload_string(xlsb, message_recv[2], n * W, n * W);
-    vector<zpshare> xbits;
-    string2vecZpshare(message_recv[2].substr(2 * n * W), xbits);
-    GPU_OK(gpu, mpcx_snn_msbl1_party_open(gpu, a, xj, n, rj));
-    rj.to_string(message_send[peer]);
-    messenger->send_and_recv(message_send, message_recv); // round 2: open r = 2a + x
-    assert(message_recv[peer].size() == n * W);
-    upload_string(rpeer, message_recv[peer]);
-    Dev<int8_t> beta0(gpu, n);
-    Dev<int64_t> R(gpu, n);
-    GPU_OK(gpu, mpcx_snn_msbl1_party_pc_inputs(gpu, rj, rpeer, 0, n, s01, beta0, R));
-    vector<int8_t> beta0_h(n), dummy;
-    vector<int64_t> R_h(n);
-    beta0.down(beta0_h.data(), n);
-    R.down(R_h.data(), n);
-    privateCompare(xbits, beta0_h, R_h, dummy); // round 3
-    message_send[2].clear();
-    message_send[peer].clear();
-    messenger->send_and_recv(message_send, message_recv); // round 4: share of beta'
-    assert(message_recv[2].size() == n * W);
-    Dev<int64_t> beta1(gpu, n), gamma(gpu, n), delta(gpu, n);
-    upload_string(beta1, message_recv[2]);
-    GPU_OK(gpu, mpcx_snn_msbl1_party_mid(gpu, (int)party_id, beta1, xlsb, beta0, R, n, gamma, delta));
-    vector<int64_t> gamma_h(n), delta_h(n), theta_h;
-    gamma.down(gamma_h.data(), n);
-    delta.down(delta_h.data(), n);
-    vector_mul(gamma_h, delta_h, theta_h); // rounds 5-6
-    Dev<int64_t> theta(gpu, theta_h.data(), n), b(gpu, n);
-    GPU_OK(gpu, mpcx_snn_msbl1_party_finish(gpu, gamma, delta, theta, n, b));
+    Dev<int64_t> a(gpu, Aj.data(), n), b(gpu, n);
+    msb_L1_dev(*this, &a, n, &b);
     b.down(Bj.data(), n);
 }
 
-// ---- msb of a in [-2^62, 2^62): convert 2a to Z_{2^64-1}, then msb_L_1
+// ---- msb of a in [-2^62, 2^62): convert 2a to Z_{2^64-1}, then msb_L_1; the intermediate stays on the device
 void SecurennEngine::msb(const vector<int64_t> &Aj, vector<int64_t> &Bj) {
     const size_t n = Aj.size();
-    vector<int64_t> twoA(n), Yj;
-    {
-        Dev<int64_t> a(gpu, Aj.data(), n), t(gpu, n);
-        GPU_OK(gpu, mpcx_ring_shl1(gpu, a, t, n));
-        t.down(twoA.data(), n);
+    Bj.assign(n, 0);
+    if (party_id == 2) {
+        share_convert_dev(*this, nullptr, n, nullptr);
+        msb_L1_dev(*this, nullptr, n, nullptr);
+        return;
     }
-    shareConvert(twoA, Yj);
-    msb_L_1(Yj, Bj);
+    Dev<int64_t> a(gpu, Aj.data(), n), twoA(gpu, n), y(gpu, n), b(gpu, n);
+    GPU_OK(gpu, mpcx_ring_shl1(gpu, a, twoA, n));
+    share_convert_dev(*this, &twoA, n, &y);
+    msb_L1_dev(*this, &y, n, &b);
+    b.down(Bj.data(), n);
 }
