@@ -1,7 +1,7 @@
 // CPU ORACLE -- TEST INFRASTRUCTURE ONLY.
 //
 // A single-threaded CPU restatement of the per-party local arithmetic of the
-// reference's ABY3Engine / SecurennEngine / PRgenerator (victerying/mpc).  It is
+// reference's ABY3Engine / SecurennEngine / MyEngine / PRgenerator (victerying/mpc).  It is
 // written deliberately in the reference's own "one byte per bit", element-at-a-
 // time style so that it is an independent check on the packed / fused HIP
 // kernels.  Nothing in the product (mpc_amd/, include/) may call, link or load

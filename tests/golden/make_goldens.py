@@ -16,8 +16,9 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 
+import my_protocols as mp  # noqa: E402
 import protocols as pr  # noqa: E402
-from backends import OracleBackend  # noqa: E402
+from my_backends import OracleMy  # noqa: E402
 from oracle_lib import cks, prg_pops  # noqa: E402
 
 
@@ -75,10 +76,24 @@ def build(be):
     C = pr.aby3_bit_inject(w, Xs, Zb)
     g["aby3_relu_1000"] = dict(msb_share0=[cks(Zb[j][0]) for j in range(3)], C_share0=[cks(C[j][0]) for j in range(3)],
                                C_share1=[cks(C[j][1]) for j in range(3)], log=log_cks(w))
+
+    # MyEngine: 64x64 product of the config-1 inputs, and msb + bit_inject at the reference benchmark's n = 2000
+    n = 64
+    w = pr.World(be)
+    Zs = mp.my_matmul(w, mp.my_share(w, X, n * n), mp.my_share(w, Y, n * n), n, n, n)
+    g["my_matmul_64"] = dict(Z_share=[cks(Zs[j]) for j in range(2)], Z_plain=cks(mp.my_reveal(w, Zs)), log=log_cks(w))
+    n = 2000
+    Xv = prg_pops(93, 0, n) // 2
+    Xv[:5] = [0, -1, -2, -(1 << 62), (1 << 62) - 1]
+    w = pr.World(be)
+    Xs = mp.my_share(w, Xv, n)
+    A = mp.my_msb(w, Xs)
+    Zi = mp.my_bit_inject(w, Xs, A)
+    g["my_relu_2000"] = dict(msb_share=[cks(A[j]) for j in range(2)], Z_share=[cks(Zi[j]) for j in range(2)], log=log_cks(w))
     return g
 
 
 if __name__ == "__main__":
     out = os.path.join(HERE, "oracle_goldens.json")
-    json.dump(build(OracleBackend()), open(out, "w"), indent=1)
+    json.dump(build(OracleMy()), open(out, "w"), indent=1)
     print("wrote", out)

@@ -1,14 +1,19 @@
 """GPU parity tests of the MyEngine path (run with -m gpu on an MI355X): every HIP segment, called through the
 C ABI, against the CPU oracle, message by message, plus the identities of test/test_Myengine.cpp."""
+import json
+import os
+
 import numpy as np
 import pytest
 
 import my_protocols as mp
 import protocols as pr
-from oracle_lib import KEY01, KEY12, KEY20, KEYS, prg_pops
+from oracle_lib import KEY01, KEY12, KEY20, KEYS, cks, prg_pops
 from test_oracle_my import _pc_case
 
 pytestmark = pytest.mark.gpu
+
+GOLD = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_goldens.json")))
 
 
 @pytest.fixture(scope="module")
@@ -126,3 +131,19 @@ def test_my_relu_chain_parity(gpu, orm, n):
     w = res[0][0]
     assert np.array_equal(mp.my_reveal_bools(w, res[0][1]), (X < 0).astype(np.int8))
     assert np.array_equal(mp.my_reveal(w, res[0][2]), X * (X < 0))
+    if n == 2000:
+        g = GOLD["my_relu_2000"]
+        assert [cks(res[0][2][j]) for j in range(2)] == g["Z_share"]
+        assert [[t, cks(m)] for t, m in w.log] == g["log"]
+
+
+def test_my_matmul_config_golden(gpu, orm):
+    n = 64
+    wd = prg_pops(20, 0, 2 * n * n)
+    X, Y = wd[: n * n].copy(), wd[n * n:].copy()
+    w = pr.World(gpu)
+    Zs = mp.my_matmul(w, mp.my_share(w, X, n * n), mp.my_share(w, Y, n * n), n, n, n)
+    g = GOLD["my_matmul_64"]
+    assert [cks(Zs[j]) for j in range(2)] == g["Z_share"]
+    assert cks(mp.my_reveal(w, Zs)) == g["Z_plain"]
+    assert [[t, cks(m)] for t, m in w.log] == g["log"]

@@ -73,3 +73,17 @@ def test_my_msb_and_bit_inject(be, n):
     assert np.array_equal(mp.my_reveal_bools(w, A), (X < 0).astype(np.int8))
     Z = mp.my_bit_inject(w, Xs, A)
     assert np.array_equal(mp.my_reveal(w, Z), X * (X < 0))
+
+
+def test_my_goldens_reproduce(be):
+    """The committed MyEngine goldens are what tests/golden/make_goldens.py produces from the oracle today."""
+    import json
+    import os
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "golden"))
+    import make_goldens
+    gold = json.load(open(os.path.join(here, "golden", "oracle_goldens.json")))
+    fresh = make_goldens.build(be)
+    for k in ("my_matmul_64", "my_relu_2000"):
+        assert fresh[k] == gold[k]
