@@ -147,3 +147,27 @@ def test_my_matmul_config_golden(gpu, orm):
     assert [cks(Zs[j]) for j in range(2)] == g["Z_share"]
     assert cks(mp.my_reveal(w, Zs)) == g["Z_plain"]
     assert [[t, cks(m)] for t, m in w.log] == g["log"]
+
+
+def test_my_errors_and_device_pool(gpu):
+    """Bad arguments come back as errors with a message (no kernel is launched); freed device blocks are recycled
+    and a pointer the context does not own is refused."""
+    import ctypes
+
+    from mpc_amd import MpcxError
+    one = np.zeros(1, dtype=np.int64)
+    with pytest.raises(MpcxError, match="party"):
+        gpu._go("my_beaver_party_finish_vecmul", 2, KEY20, one, np.zeros(2, np.int64), np.zeros(2, np.int64), 1, 0, 1,
+                ("out", np.int64, 1))
+    with pytest.raises(MpcxError, match="range outside"):
+        gpu._go("my_beaver_dealer_vecmul", KEY20, KEY12, KEYS, 4, 3, 2, ("out", np.int64, 2), ("out", np.int64, 2))
+    with pytest.raises(MpcxError, match="empty shape"):
+        gpu._go("my_beaver_dealer_matmul", KEY20, KEY12, KEYS, 0, 1, 1, ("out", np.int64, 1), ("out", np.int64, 1))
+    ctx = gpu.ctx
+    a = ctx.empty(np.int64, 1000)
+    p = a.ptr
+    a.free()
+    b = ctx.empty(np.int64, 1000)  # same size class: the block just freed
+    assert b.ptr == p
+    with pytest.raises(MpcxError, match="not allocated"):
+        ctx._call("mpcx_free", ctypes.c_void_p(p + 64))
