@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <map>
 #include <string>
 #include <utility>
@@ -112,6 +113,20 @@ void prg_rand_cache_clear(mpcx_ctx *ctx);
 // second[i][k] = (bit_k(v[i]) + 67 - first[i][k]) % 67; first / second are 16-byte aligned
 int snn_bit_share_launch(mpcx_ctx *ctx, const u64 *v, const u8 *rnd, u64 n, u16 *first, u16 *second);
 static inline u64 ceil_div(u64 a, u64 b) { return (a + b - 1) / b; }
+// Largest grid the streaming kernels are launched with.  They all grid-stride, but for the privateCompare and
+// element-wise kernels a launch with one item per lane (hundreds of thousands of small workgroups) streams
+// measurably faster on MI355X than a capped, looping one (privateCompare helper at 2^24 elements: 6.2 vs
+// 4.9 TB/s), so their cap is only the API limit; kernels that measured otherwise keep their own smaller cap.
+// The environment variable MPCX_MAX_GRID lowers the limit, which is how the tests exercise the loops.
+static inline u64 mpcx_max_grid() {
+    static const u64 v = [] {
+        const char *e = getenv("MPCX_MAX_GRID");
+        const u64 x = e ? strtoull(e, nullptr, 10) : 0;
+        return x ? x : 0x7FFFFFFFull;
+    }();
+    return v;
+}
+#define MPCX_MAX_GRID mpcx_max_grid()
 
 // Z (+)= [A_1 | A_2 | ..] * [B_1 (+Bplus_1) ; B_2 ; ..] (+ add - sub): a ring product whose K dimension is the
 // concatenation of `nparts` (A_p : r x l, B_p : l x c) pairs.  add/sub are row-major r*c word arrays.

@@ -24,7 +24,7 @@ template <class F> __global__ __launch_bounds__(256) void ew_kernel(u64 n, F f) 
 template <class F> int ew_launch(mpcx_ctx *ctx, u64 n, F f) {
     if (n == 0) return 0;
     u64 blocks = ceil_div(n, 256);
-    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (blocks > MPCX_MAX_GRID) blocks = MPCX_MAX_GRID;
     hipLaunchKernelGGL(ew_kernel<F>, dim3((u32)blocks), dim3(256), 0, ctx->stream, n, f);
     MPCX_LAUNCH_CHECK();
     return 0;

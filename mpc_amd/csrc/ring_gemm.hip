@@ -370,7 +370,7 @@ int ring_gemm_parts(mpcx_ctx *ctx, const GemmPart *parts, int nparts, u64 r, u64
                                    tiles_m, tiles_n, gm);
         }
         const u64 total = r * c;
-        const u32 grid = (u32)(ceil_div(total, 256) < 4096 ? ceil_div(total, 256) : 4096);
+        const u32 grid = (u32)(ceil_div(total, 256) < MPCX_MAX_GRID ? ceil_div(total, 256) : MPCX_MAX_GRID);
         const bool last = kb + lc >= l;
         ProfScope pc(ctx, PROF_COMBINE);
         hipLaunchKernelGGL(combine_kernel, dim3(grid), dim3(256), 0, ctx->stream, Cpl, Mp, Np, r, c,

@@ -5,6 +5,8 @@
 // 8 whole elements per 1 KiB load/store and the running sum over bit positions is a short suffix
 // scan across the 8 lanes of a group.  Randomness that the reference reads from PRgenerator::int_buff
 // is regenerated on the device from the stream checkpoints.
+#include <cstdlib>
+
 #include "mpcx_internal.h"
 
 namespace {
@@ -26,7 +28,7 @@ template <class F> __global__ __launch_bounds__(256) void ew_kernel(u64 n, F f) 
 template <class F> int ew_launch(mpcx_ctx *ctx, u64 n, F f) {
     if (n == 0) return 0;
     u64 blocks = ceil_div(n, 256);
-    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (blocks > MPCX_MAX_GRID) blocks = MPCX_MAX_GRID;
     hipLaunchKernelGGL(ew_kernel<F>, dim3((u32)blocks), dim3(256), 0, ctx->stream, n, f);
     MPCX_LAUNCH_CHECK();
     return 0;
@@ -164,7 +166,7 @@ __global__ __launch_bounds__(256) void bit_share_kernel(const u64 *__restrict__ 
 
 inline u32 grid_for(u64 work) {
     u64 b = ceil_div(work, 256);
-    if (b > 8192) b = 8192;
+    if (b > MPCX_MAX_GRID) b = MPCX_MAX_GRID;
     if (b == 0) b = 1;
     return (u32)b;
 }
