@@ -40,10 +40,25 @@ struct u16x8 {
     __device__ void set(int j, u32 v) { w[j >> 1] = (w[j >> 1] & ~(0xFFFFu << (16 * (j & 1)))) | (v << (16 * (j & 1))); }
 };
 
+// x % 67 for x < 2^16 without a wide multiply: floor(x / 67) = (x * ceil(2^22 / 67)) >> 22 exactly while
+// x * 30 < 2^22 (30 = 62602 * 67 - 2^22), and the product stays below 2^32; three full-rate 24-bit operations.
+// (HIP declares __umul24 with a signed result: convert before shifting.)
+__device__ inline u32 mul24(u32 a, u32 b) { return (u32)__umul24(a, b); }
+__device__ inline u32 mod67_u16(u32 x) {
+    const u32 q = mul24(x, 62602u) >> 22;
+    return x - mul24(q, P);
+}
+
 // privateCompare, party 0/1 (SecurennEngine.cpp:543-592).  One piece = 8 bit positions of one element.
 // S / U: one byte per value, already reduced mod 67 with 0 -> 1 (:523-534).
 // variant 1 = MyEngine::privateCompare (MyEngine.cpp:316-353): the same two formulas, chosen by beta == 0 alone
 // (any other beta compares against r + 1, which wraps to 0 for r = -1); U is not read.
+//
+// The reference stores every intermediate in a uint16_t before reducing it mod 67, and inputs are not required to
+// be below 67, so the truncations are kept: with xm = x % 67, bit b of r (beta = 0) or of r + 1 (beta = 1):
+//   w = b ? ((66 x + party) mod 2^16) % 67 : xm                                            (:561-562, :569-570)
+//   c = ((beta = 0 ? (66 x) % 67 + party b + party : 66 party b + x + party) + sum_w) mod 2^16 % 67   (:559, :567)
+// where (66 x) % 67 = (67 - xm) % 67 because the reference reduces that product before it is truncated.
 __global__ __launch_bounds__(256) void pc_party_kernel(int party, int variant, const uint4 *__restrict__ xbits, const i8 *__restrict__ beta,
                                                        const i64 *__restrict__ r, const u64 *__restrict__ S,
                                                        const u64 *__restrict__ U, u64 n, uint4 *__restrict__ d_out) {
@@ -56,31 +71,30 @@ __global__ __launch_bounds__(256) void pc_party_kernel(int party, int variant, c
         const u64 i = live ? c >> 3 : 0;
         const u32 q = (u32)(c & 7);
         u16x8 x{}, d{};
-        u64 sb = 0, ub = 0;
+        uint2 sb = make_uint2(0, 0); // the 8 s bytes of this lane's positions
         u64 rv = 0;
         int bt = 0;
         if (live) {
             const uint4 xv = xbits[c];
             x.w[0] = xv.x, x.w[1] = xv.y, x.w[2] = xv.z, x.w[3] = xv.w;
-            sb = S[c];
+            sb = ((const uint2 *)S)[c];
             rv = (u64)r[i];
             bt = beta[i];
         }
-        const u64 tv = rv + 1;
         const int mode = (bt == 0) ? 0 : ((variant == 1 || (bt == 1 && rv != ~0ull)) ? 1 : 2);
-        u32 wv[8], cv[8];
+        // the 8 bits of r (mode 0) or r + 1 (mode 1) this lane works on
+        const u32 bits8 = (u32)(((mode == 0 ? rv : rv + 1) >> (8 * q)) & 0xFF);
+        u32 xm[8], wv[8];
         u32 tot = 0;
-        if (mode != 2) {
-            const u64 bits = mode == 0 ? rv : tv;
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const u32 xk = x.get(j);
-                const u32 b = (u32)((bits >> (8 * q + j)) & 1);
-                // W = X + party*b + 65*b*X, stored to uint16 then % 67 (:561-562, :569-570)
-                wv[j] = ((xk + pid * b + (P - 2) * b * xk) & 0xFFFF) % P;
-                tot += wv[j];
-            }
+        for (int j = 0; j < 8; j++) {
+            const u32 xk = x.get(j);
+            xm[j] = mod67_u16(xk);
+            const u32 w1 = mod67_u16((mul24(xk, P - 1) + pid) & 0xFFFF);
+            wv[j] = ((bits8 >> j) & 1) ? w1 : xm[j];
+            tot += wv[j];
         }
+        if (mode == 2) tot = 0;
         // sum of W over all higher bit positions: suffix scan over the 8 lanes of the element
         u32 incl = tot;
 #pragma unroll
@@ -89,30 +103,30 @@ __global__ __launch_bounds__(256) void pc_party_kernel(int party, int variant, c
             if (q + dlt < 8) incl += t;
         }
         u32 run = incl - tot; // W of the lanes above this one
-        if (mode == 2 && live) ub = U[c];
+        const u32 add1 = mode == 0 ? pid : (P - 1) * pid; // coefficient of the bit
 #pragma unroll
         for (int j = 7; j >= 0; j--) {
-            const u32 xk = x.get(j);
-            u32 ck;
-            if (mode == 0) {
-                const u32 b = (u32)((rv >> (8 * q + j)) & 1);
-                ck = ((xk * (P - 1)) % P + pid * b + pid + (run & 0xFFFF)) & 0xFFFF; // :559
-                ck %= P;
-                run += wv[j];
-            } else if (mode == 1) {
-                const u32 b = (u32)((tv >> (8 * q + j)) & 1);
-                ck = ((P - 1) * pid * b + xk + pid + (run & 0xFFFF)) & 0xFFFF; // :567
-                ck %= P;
-                run += wv[j];
-            } else {
-                const u32 uk = (u32)((ub >> (8 * j)) & 0xFF);
-                if (q != 0 || j != 0)
-                    ck = (((1 - pid) * (1 + uk) + (P - pid) * uk) & 0xFFFF) % P; // :577-578
+            const u32 b = (bits8 >> j) & 1;
+            const u32 pre = mode == 0 ? (xm[j] ? P - xm[j] : 0u) : x.get(j);
+            const u32 ck = mod67_u16((pre + (b ? add1 : 0u) + pid + run) & 0xFFFF);
+            run += wv[j];
+            const u32 sk = ((j < 4 ? sb.x : sb.y) >> (8 * (j & 3))) & 0xFF;
+            d.set(j, mod67_u16(mul24(sk, ck))); // :589-590 (both factors are below 67)
+        }
+        if (__any(mode == 2)) { // beta = 1 and r = -1 (:574-584): c comes from u alone
+            uint2 ub = make_uint2(0, 0);
+            if (mode == 2 && live) ub = ((const uint2 *)U)[c];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const u32 uk = ((j < 4 ? ub.x : ub.y) >> (8 * (j & 3))) & 0xFF;
+                u32 ck;
+                if (q != 0 || j != 0) // :577-578: (1 - party)(1 + u) + (67 - party) u, below 2^16 for u < 67
+                    ck = mod67_u16(pid == 0 ? 1 + mul24(P + 1, uk) : mul24(P - 1, uk));
                 else
                     ck = pid == 0 ? uk : P - uk; // :582
+                const u32 sk = ((j < 4 ? sb.x : sb.y) >> (8 * (j & 3))) & 0xFF;
+                if (mode == 2) d.set(j, mod67_u16(mul24(sk, ck)));
             }
-            const u32 sk = (u32)((sb >> (8 * j)) & 0xFF);
-            d.set(j, ((sk * ck) & 0xFFFF) % P); // :589-590
         }
         if (live) d_out[c] = make_uint4(d.w[0], d.w[1], d.w[2], d.w[3]);
     }
