@@ -78,8 +78,8 @@ __global__ __launch_bounds__(256) void split_limbs_kernel(const u64 *__restrict_
 // byte feeds 192 multiply-adds (a plain one-accumulator 256x256 tiling feeds 128), and the accumulators
 // are written out once, after the whole K loop.
 //
-// Staging is LDS-DMA (global_load_lds, 16 B per lane) into two 48 KiB buffers (step t+1 lands while step t
-// is multiplied).  A DMA wave-instruction writes 1 KiB linearly = 32 rows x 32 B, so the bank swizzle
+// Staging is LDS-DMA (global_load_lds, 16 B per lane) into three 48 KiB buffers (steps t+1 and t+2 land while
+// step t is multiplied).  A DMA wave-instruction writes 1 KiB linearly = 32 rows x 32 B, so the bank swizzle
 // is applied to the per-lane SOURCE address and undone on the ds_read: 16-byte half h of row r is kept
 // at half h ^ ((r >> 3) & 1), which spreads the 16 rows of a ds_read_b128 lane group over all 64 banks.
 //
@@ -92,7 +92,7 @@ template <int ABL>
 __global__ __launch_bounds__(512) void limb_gemm_kernel(const i8 *__restrict__ Apl, const i8 *__restrict__ Bpl,
                                                         i32 *__restrict__ Cpl, u32 Mp, u32 Np, u32 nkb, u32 tiles_m,
                                                         u32 tiles_n, u32 GM) {
-    __shared__ __attribute__((aligned(1024))) i8 lds[2 * STAGE_BYTES]; // 96 KiB: two staging buffers
+    __shared__ __attribute__((aligned(1024))) i8 lds[3 * STAGE_BYTES]; // 144 KiB: three staging buffers
     const u32 tid = threadIdx.x, lane = tid & 63;
     const u32 wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const u32 wm = wid >> 1, wn = wid & 1, lr = lane & 31, lh = lane >> 5;
@@ -131,14 +131,12 @@ __global__ __launch_bounds__(512) void limb_gemm_kernel(const i8 *__restrict__ A
             ldst[q] = 8 * RM * RK + limb * (RN * RK) + half * 1024;
         }
     }
-    auto stage = [&](u32 buf) {
-#pragma unroll
-        for (u32 q = 0; q < 6; q++) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc[q],
-                                             (__attribute__((address_space(3))) void *)(lds + buf * STAGE_BYTES + ldst[q]),
-                                             16, 0, 0);
-            gsrc[q] += gstep[q];
-        }
+    // one DMA piece (1 KiB per wave instruction) of this wave's six
+    auto stage_piece = [&](u32 buf, u32 q) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc[q],
+                                         (__attribute__((address_space(3))) void *)(lds + buf * STAGE_BYTES + ldst[q]), 16,
+                                         0, 0);
+        gsrc[q] += gstep[q];
     };
 
     // ---- fragment addresses (the swizzle term only depends on the lane)
@@ -152,62 +150,98 @@ __global__ __launch_bounds__(512) void limb_gemm_kernel(const i8 *__restrict__ A
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[s][r] = 0;
 
-    // Software pipeline with ONE barrier per K step, placed in the middle of the step's MFMA stream:
-    //   first part : MFMAs with A limbs 0..3 (26 of 36) while the remaining A fragments of this step are read;
-    //   barrier    : by now every wave has read ALL its fragments of step kb (they sit in registers) and its
-    //                DMA pieces of step kb+1 have landed (vmcnt(0)), so after the barrier the buffer of step kb
-    //                is free and step kb+1 is visible to everyone;
-    //   second part: re-fill the freed buffer with step kb+2, read the first fragments of step kb+1, and issue
-    //                the last 10 MFMAs (A limbs 4..7) of step kb from registers.
-    // The matrix pipe therefore never waits for LDS right after a barrier.
+    // Software pipeline, three staging buffers, ONE barrier per K step placed in the middle of the step's MFMAs:
+    //   first part : the 26 MFMAs with A limbs 0..3; the A fragments 1..7 of this step are read at its start;
+    //   barrier    : every wave has all its fragments of step kb in registers and its DMA pieces of step kb+1
+    //                have landed (counted vmcnt), so step kb+1 becomes visible to everyone;
+    //   second part: the first fragments of step kb+1 are read while the last 10 MFMAs (A limbs 4..7) run from
+    //                registers, so the matrix pipe never waits for LDS right after a barrier.
+    // The six DMA pieces a wave issues for step kb+2 go to the buffer step kb-1 used (free since the previous
+    // barrier).  A DMA piece costs its wave on the order of 100 issue cycles, so the pieces are spread singly
+    // between MFMAs (four in the first part, two in the second) instead of being issued as one burst after the
+    // barrier, where all eight waves would stall the matrix pipes together; each has more than half a step to land.
     auto rdA = [&](u32 buf, u32 i) { return *(const v4i *)(lds + buf * STAGE_BYTES + a_off + i * (RM * RK)); };
     auto rdB = [&](u32 buf, u32 j) { return *(const v4i *)(lds + buf * STAGE_BYTES + b_off + j * (RN * RK)); };
+#define MPCX_PIN() __builtin_amdgcn_sched_barrier(0)
     v4i b[8], a0;
     if (ABL != 2) {
-        stage(0);
+#pragma unroll
+        for (u32 q = 0; q < 6; q++) stage_piece(0, q);
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-        if (nkb > 1) stage(1);
+        if (nkb > 1) {
+#pragma unroll
+            for (u32 q = 0; q < 6; q++) stage_piece(1, q);
+        }
     }
 #pragma unroll
     for (u32 j = 0; j < 8; j++) b[j] = rdB(0, j);
     a0 = rdA(0, 0);
     u32 cur = 0;
     for (u32 kb = 0; kb < nkb; kb++) {
+        const u32 nxt = cur == 2 ? 0 : cur + 1;  // buffer of step kb+1
+        const u32 fill = cur == 0 ? 2 : cur - 1; // buffer of step kb+2 (= of step kb-1)
+        const bool more = (kb + 2 < nkb) && ABL != 2;
         v4i a[8];
         a[0] = a0;
-        if (ABL != 1) {
 #pragma unroll
-            for (u32 i = 1; i < 8; i++) a[i] = rdA(cur, i);
+        for (u32 i = 1; i < 8; i++) a[i] = rdA(cur, i);
+        if (ABL != 1) {
+            u32 m = 0;
 #pragma unroll
             for (u32 i = 0; i < 4; i++)
 #pragma unroll
-                for (u32 j = 0; j + i < 8; j++)
+                for (u32 j = 0; j + i < 8; j++) {
                     acc[i + j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[i], b[j], acc[i + j], 0, 0, 0);
+                    m++;
+                    if (m == 4 || m == 10 || m == 16 || m == 22) { // m is a compile-time value after unrolling
+                        MPCX_PIN();
+                        if (more) stage_piece(fill, (m - 4) / 6);
+                        MPCX_PIN();
+                    }
+                }
+        } else if (more) {
+#pragma unroll
+            for (u32 q = 0; q < 4; q++) stage_piece(fill, q);
         }
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (kb + 2 < nkb && ABL != 2) stage(cur);
+        // step kb+1's six pieces are older than the (up to four) just issued
+        if (more)
+            asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         v4i bn[8], an0;
         if (kb + 1 < nkb) {
 #pragma unroll
-            for (u32 j = 0; j < 8; j++) bn[j] = rdB(cur ^ 1, j);
-            an0 = rdA(cur ^ 1, 0);
+            for (u32 j = 0; j < 8; j++) bn[j] = rdB(nxt, j);
+            an0 = rdA(nxt, 0);
         } else {
 #pragma unroll
             for (u32 j = 0; j < 8; j++) bn[j] = b[j];
             an0 = a0;
         }
         if (ABL != 1) {
+            u32 m = 0;
 #pragma unroll
             for (u32 i = 4; i < 8; i++)
 #pragma unroll
-                for (u32 j = 0; j + i < 8; j++)
+                for (u32 j = 0; j + i < 8; j++) {
                     acc[i + j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[i], b[j], acc[i + j], 0, 0, 0);
+                    m++;
+                    if (m == 3 || m == 7) {
+                        MPCX_PIN();
+                        if (more) stage_piece(fill, m == 3 ? 4 : 5);
+                        MPCX_PIN();
+                    }
+                }
+        } else if (more) {
+            stage_piece(fill, 4);
+            stage_piece(fill, 5);
         }
 #pragma unroll
         for (u32 j = 0; j < 8; j++) b[j] = bn[j];
         a0 = an0;
-        cur ^= 1;
+        cur = nxt;
     }
+#undef MPCX_PIN
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 
     const u64 strideC = (u64)Mp * Np;
