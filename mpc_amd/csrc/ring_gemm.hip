@@ -13,6 +13,7 @@
 // Limb planes are stored K-blocked: plane[i][kb][row][32 bytes], kb = k / 32, so that the operand
 // tile of one K step (a run of rows x 32 bytes) is one contiguous, fully used piece of memory.
 #include <cstdlib>
+#include <type_traits>
 
 #include "mpcx_internal.h"
 
@@ -114,26 +115,26 @@ __global__ __launch_bounds__(512) void limb_gemm_kernel(const i8 *__restrict__ A
     // pieces 32..47: B limb (p-32)/2, rows 32*((p-32)%2)..
     const u32 lrow = lane >> 1;
     const u32 lsrc = lrow * RK + (((lane & 1) ^ ((lrow >> 3) & 1)) << 4); // swizzled source offset inside a piece
-    const i8 *gsrc[6];
+    const i8 *gsrc[6]; // wave-uniform piece bases (scalar registers); the lane offset lsrc is added at the load
     u32 gstep[6], ldst[6];
 #pragma unroll
     for (u32 q = 0; q < 6; q++) {
         const u32 p = wid * 6 + q;
         if (p < 32) {
             const u32 limb = p >> 2, quarter = p & 3;
-            gsrc[q] = Apl + ((u64)limb * nkb * Mp + (u64)tm * RM + quarter * 32) * RK + lsrc;
+            gsrc[q] = Apl + ((u64)limb * nkb * Mp + (u64)tm * RM + quarter * 32) * RK;
             gstep[q] = Mp * RK;
             ldst[q] = limb * (RM * RK) + quarter * 1024;
         } else {
             const u32 limb = (p - 32) >> 1, half = (p - 32) & 1;
-            gsrc[q] = Bpl + ((u64)limb * nkb * Np + (u64)tn * RN + half * 32) * RK + lsrc;
+            gsrc[q] = Bpl + ((u64)limb * nkb * Np + (u64)tn * RN + half * 32) * RK;
             gstep[q] = Np * RK;
             ldst[q] = 8 * RM * RK + limb * (RN * RK) + half * 1024;
         }
     }
     // one DMA piece (1 KiB per wave instruction) of this wave's six
     auto stage_piece = [&](u32 buf, u32 q) {
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc[q],
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gsrc[q] + lsrc),
                                          (__attribute__((address_space(3))) void *)(lds + buf * STAGE_BYTES + ldst[q]), 16,
                                          0, 0);
         gsrc[q] += gstep[q];
@@ -177,12 +178,15 @@ __global__ __launch_bounds__(512) void limb_gemm_kernel(const i8 *__restrict__ A
     for (u32 j = 0; j < 8; j++) b[j] = rdB(0, j);
     a0 = rdA(0, 0);
     u32 cur = 0;
-    for (u32 kb = 0; kb < nkb; kb++) {
+    // one K step: multiplies with the fragments in (bu, au0), leaves the first fragments of the next step in
+    // (bnx, anx0).  The two register sets swap roles every step (nkb is even), so no fragment is ever copied.
+    // `more_tag`: whether a step kb+2 exists to be staged (true in the main loop, false in the two tail steps).
+    auto step = [&](auto more_tag, const v4i(&bu)[8], const v4i &au0, v4i(&bnx)[8], v4i &anx0, bool last) {
         const u32 nxt = cur == 2 ? 0 : cur + 1;  // buffer of step kb+1
         const u32 fill = cur == 0 ? 2 : cur - 1; // buffer of step kb+2 (= of step kb-1)
-        const bool more = (kb + 2 < nkb) && ABL != 2;
+        constexpr bool more = decltype(more_tag)::value && ABL != 2;
         v4i a[8];
-        a[0] = a0;
+        a[0] = au0;
 #pragma unroll
         for (u32 i = 1; i < 8; i++) a[i] = rdA(cur, i);
         if (ABL != 1) {
@@ -191,7 +195,7 @@ __global__ __launch_bounds__(512) void limb_gemm_kernel(const i8 *__restrict__ A
             for (u32 i = 0; i < 4; i++)
 #pragma unroll
                 for (u32 j = 0; j + i < 8; j++) {
-                    acc[i + j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[i], b[j], acc[i + j], 0, 0, 0);
+                    acc[i + j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[i], bu[j], acc[i + j], 0, 0, 0);
                     m++;
                     if (m == 4 || m == 10 || m == 16 || m == 22) { // m is a compile-time value after unrolling
                         MPCX_PIN();
@@ -208,15 +212,10 @@ __global__ __launch_bounds__(512) void limb_gemm_kernel(const i8 *__restrict__ A
             asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         else
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        v4i bn[8], an0;
-        if (kb + 1 < nkb) {
+        if (!last) {
 #pragma unroll
-            for (u32 j = 0; j < 8; j++) bn[j] = rdB(nxt, j);
-            an0 = rdA(nxt, 0);
-        } else {
-#pragma unroll
-            for (u32 j = 0; j < 8; j++) bn[j] = b[j];
-            an0 = a0;
+            for (u32 j = 0; j < 8; j++) bnx[j] = rdB(nxt, j);
+            anx0 = rdA(nxt, 0);
         }
         if (ABL != 1) {
             u32 m = 0;
@@ -224,7 +223,7 @@ __global__ __launch_bounds__(512) void limb_gemm_kernel(const i8 *__restrict__ A
             for (u32 i = 4; i < 8; i++)
 #pragma unroll
                 for (u32 j = 0; j + i < 8; j++) {
-                    acc[i + j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[i], b[j], acc[i + j], 0, 0, 0);
+                    acc[i + j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[i], bu[j], acc[i + j], 0, 0, 0);
                     m++;
                     if (m == 3 || m == 7) {
                         MPCX_PIN();
@@ -236,11 +235,19 @@ __global__ __launch_bounds__(512) void limb_gemm_kernel(const i8 *__restrict__ A
             stage_piece(fill, 4);
             stage_piece(fill, 5);
         }
-#pragma unroll
-        for (u32 j = 0; j < 8; j++) b[j] = bn[j];
-        a0 = an0;
         cur = nxt;
+    };
+    v4i b2[8], a02;
+#pragma unroll
+    for (u32 j = 0; j < 8; j++) b2[j] = b[j];
+    a02 = a0;
+    // nkb is even (K is padded to a multiple of 64): pairs of steps, the last pair stages nothing
+    for (u32 kb = 0; kb + 2 < nkb; kb += 2) {
+        step(std::true_type{}, b, a0, b2, a02, false);
+        step(std::true_type{}, b2, a02, b, a0, false);
     }
+    step(std::false_type{}, b, a0, b2, a02, false);
+    step(std::false_type{}, b2, a02, b, a0, true);
 #undef MPCX_PIN
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 
