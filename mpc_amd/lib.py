@@ -6,7 +6,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmpcx.so")
+LIB_PATH = os.environ.get("MPCX_LIBRARY") or os.path.join(_HERE, "libmpcx.so")  # override: A/B runs of two builds
 
 _lib = None
 
