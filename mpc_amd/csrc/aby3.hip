@@ -194,17 +194,8 @@ int mpcx_aby3_share_local(mpcx_ctx *ctx, const int64_t *X, uint64_t n, uint64_t 
                           uint64_t seed_prev, uint64_t pop_prev, int64_t *out) {
     if (n == 0) return 0;
     MPCX_REQUIRE(out, "mpcx_aby3_share_local: out is NULL");
-    void *ws;
-    MPCX_TRY(mpcx_ws(ctx, 16 * n, &ws));
-    u64 *a = (u64 *)ws, *b = a + n;
-    MPCX_TRY(prg_fill_words(ctx, seed_next, 0, PRG_POP_T0 + pop_next, n, 1, (i64 *)a, nullptr));
-    MPCX_TRY(prg_fill_words(ctx, seed_prev, 0, PRG_POP_T0 + pop_prev, n, 1, (i64 *)b, nullptr));
-    const u64 *x = (const u64 *)X;
-    u64 *o = (u64 *)out;
-    return ew_launch(ctx, n, [=] __device__(u64 i) {
-        u64 r = a[i] - b[i];
-        o[i] = x ? r + x[i] : r;
-    });
+    // the two pop streams are regenerated, subtracted and added to X in one pass
+    return prg_fill_diff(ctx, seed_next, PRG_POP_T0 + pop_next, seed_prev, PRG_POP_T0 + pop_prev, n, X, out);
 }
 
 int mpcx_aby3_share_bools_local(mpcx_ctx *ctx, const int8_t *X, uint64_t n, uint64_t seed_next, uint64_t pop_next,
@@ -230,12 +221,12 @@ static int aby3_matmul_impl(mpcx_ctx *ctx, const i64 *X0, const i64 *X1, const i
     const u64 nz = rows * c;
     const u64 gemm_bytes = ring_gemm_ws_bytes(2, rows, l, c);
     void *ws;
-    MPCX_TRY(mpcx_ws(ctx, gemm_bytes + 16 * nz, &ws)); // the gemm driver takes the front, the mask words the tail
-    u64 *mask = (u64 *)((u8 *)ws + gemm_bytes);
-    MPCX_TRY(prg_fill_words(ctx, seed_next, 0, PRG_POP_T0 + pop_next + first_word, nz, 1, (i64 *)mask, nullptr));
-    MPCX_TRY(prg_fill_words(ctx, seed_prev, 0, PRG_POP_T0 + pop_prev + first_word, nz, 1, (i64 *)(mask + nz), nullptr));
+    MPCX_TRY(mpcx_ws(ctx, gemm_bytes + 8 * nz, &ws)); // the gemm driver takes the front, the mask words the tail
+    i64 *mask = (i64 *)((u8 *)ws + gemm_bytes);
+    MPCX_TRY(prg_fill_diff(ctx, seed_next, PRG_POP_T0 + pop_next + first_word, seed_prev, PRG_POP_T0 + pop_prev + first_word, nz,
+                           nullptr, mask));
     GemmPart parts[2] = {{X0, Y0, Y1}, {X1, Y0, nullptr}};
-    return ring_gemm_parts(ctx, parts, 2, rows, l, c, layout, layout, (const i64 *)mask, (const i64 *)(mask + nz), Z0, 0, 0);
+    return ring_gemm_parts(ctx, parts, 2, rows, l, c, layout, layout, mask, nullptr, Z0, 0, 0);
 }
 
 int mpcx_aby3_matmul_local_rows(mpcx_ctx *ctx, const int64_t *X0, const int64_t *X1, const int64_t *Y0,
@@ -262,14 +253,13 @@ int mpcx_aby3_vecmul_local(mpcx_ctx *ctx, const int64_t *X0, const int64_t *X1, 
     if (n == 0) return 0;
     MPCX_REQUIRE(X0 && X1 && Y0 && Y1 && Z0, "mpcx_aby3_vecmul_local: NULL operand");
     void *ws;
-    MPCX_TRY(mpcx_ws(ctx, 16 * n, &ws));
-    u64 *a = (u64 *)ws, *b = a + n;
-    MPCX_TRY(prg_fill_words(ctx, seed_next, 0, PRG_POP_T0 + pop_next, n, 1, (i64 *)a, nullptr));
-    MPCX_TRY(prg_fill_words(ctx, seed_prev, 0, PRG_POP_T0 + pop_prev, n, 1, (i64 *)b, nullptr));
+    MPCX_TRY(mpcx_ws(ctx, 8 * n, &ws));
+    u64 *m = (u64 *)ws;
+    MPCX_TRY(prg_fill_diff(ctx, seed_next, PRG_POP_T0 + pop_next, seed_prev, PRG_POP_T0 + pop_prev, n, nullptr, (i64 *)m));
     const u64 *x0 = (const u64 *)X0, *x1 = (const u64 *)X1, *y0 = (const u64 *)Y0, *y1 = (const u64 *)Y1;
     u64 *z = (u64 *)Z0;
     return ew_launch(ctx, n, [=] __device__(u64 i) {
-        z[i] = x0[i] * y0[i] + x0[i] * y1[i] + x1[i] * y0[i] + (a[i] - b[i]);
+        z[i] = x0[i] * y0[i] + x0[i] * y1[i] + x1[i] * y0[i] + m[i];
     });
 }
 

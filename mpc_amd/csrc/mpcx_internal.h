@@ -102,6 +102,8 @@ struct ProfScope {
 // internal launchers used across translation units (all asynchronous on ctx->stream)
 int prg_fill_words(mpcx_ctx *ctx, u64 seed, u64 lcg, u64 t_first, u64 count, u64 stride, i64 *out, i8 *bools);
 int prg_fill_buff_mod67(mpcx_ctx *ctx, u64 seed, u64 lcg, u64 first, u64 count, int zero_to_one, u8 *out);
+// out[i] = (X ? X[i] : 0) + A[tA_first + i] - B[tB_first + i] over the stream words of generators (seedA, 0), (seedB, 0)
+int prg_fill_diff(mpcx_ctx *ctx, u64 seedA, u64 tA_first, u64 seedB, u64 tB_first, u64 count, const i64 *X, i64 *out);
 // The same bytes through the context's cache: *out points at cached device memory.  Entries requested since
 // the caller last advanced ctx->rand_tick are never evicted, so a call bumps the tick once and may then hold
 // several slices.  A slice that does not fit the cache budget is generated at byte ws_offset of the context
