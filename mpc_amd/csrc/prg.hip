@@ -18,6 +18,11 @@ struct HostState {
 };
 __host__ __device__ inline u64 prv_step(u64 &seed, u64 &lcg, u64 &hash) {
     seed *= lcg * 2 + 1;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // keep the product in registers as one value: otherwise the compiler re-derives it inside `lcg += seed`
+    // with a second 64-bit multiply-add, which costs more than the plain 64-bit add it replaces
+    asm volatile("" : "+v"(seed));
+#endif
     const u64 rs = seed >> 32 | seed << 32;
     hash += rs + 0xAAAAAAAAAAAAAAAAull;
     lcg += seed + 0x5555555555555555ull;
