@@ -56,8 +56,9 @@ def prof_read(ctx, name):
 
 
 class Aby3MatmulJob:
-    def __init__(self, ctx, torch, dev, n, rank, world):
+    def __init__(self, ctx, torch, dev, n, rank, world, host_gather=False):
         self.ctx, self.torch, self.n, self.rank, self.world = ctx, torch, n, rank, world
+        self.host_gather = host_gather
         self.rows, self.l, self.c = n, n, n
         self.rows_total = n * world
         self.row0, rows = matmul_row_block(self.rows_total, world, rank)
@@ -98,7 +99,12 @@ class Aby3MatmulJob:
         if self.world > 1:
             import torch.distributed as dist
             for j in range(3):  # the message party j hands to the messenger: all row-blocks of Z0
-                dist.all_gather_into_tensor(self.Zfull[j], self.Z0[j])
+                if self.host_gather:  # rehearsal without RCCL (gloo): through host memory
+                    parts = [self.torch.empty(self.Z0[j].numel(), dtype=self.torch.int64) for _ in range(self.world)]
+                    dist.all_gather(parts, self.Z0[j].cpu())
+                    self.Zfull[j].copy_(self.torch.cat(parts))
+                else:
+                    dist.all_gather_into_tensor(self.Zfull[j], self.Z0[j])
         for j in range(3):
             ctx.call("aby3_reveal3", self.Z0[(j + 2) % 3], self.Z0[j], self.Z0[(j + 1) % 3], self.Zplain[j],
                      self.rows * self.c)
@@ -279,11 +285,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--n", type=int, default=4096)
+    ap.add_argument("--size", type=int, default=4096, help="matrix dimension per GPU (rows of the row-block, l and c)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-bitwise", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="development only: skip the result check")
     ap.add_argument("--bitwise-log2n", type=int, default=24, help="elements of the privateCompare / msb / ReLU runs")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo: rehearsal of the multi-rank path on fewer GPUs than ranks (gathers through the host)")
     args = ap.parse_args()
 
     import torch
@@ -292,18 +300,22 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank if args.dist_backend == "nccl" else local_rank % torch.cuda.device_count()
+    dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     from mpc_amd import Context
-    ctx = Context(local_rank)
+    ctx = Context(dev_index)
     ctx.call("set_stream", torch.cuda.current_stream().cuda_stream)
 
-    job = Aby3MatmulJob(ctx, torch, dev, args.n, rank, world)
+    job = Aby3MatmulJob(ctx, torch, dev, args.size, rank, world, host_gather=args.dist_backend == "gloo")
 
     def barrier():
         if dist is not None:
@@ -320,7 +332,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     gemm_ms, gemm_cnt = prof_read(ctx, "limb_gemm")
@@ -346,7 +358,7 @@ def main():
                                    "inputs from PRgenerator(20,0)",
                        "rows_per_gpu": job.rows, "parallelism": f"row-block x{world}" if world > 1 else "single GPU"},
             "roofline": {"bound": "mfma", "kernel": "limb_gemm_kernel", "achieved": achieved, "peak": INT8_PEAK_TOPS,
-                         "unit": "TFLOP/s", "frac": achieved / INT8_PEAK_TOPS, "traffic": measured_traffic(args.n, world),
+                         "unit": "TFLOP/s", "frac": achieved / INT8_PEAK_TOPS, "traffic": measured_traffic(args.size, world),
                          "traffic_unit": "bytes per launch (profiles/r1_pmc_summary.json)",
                          "avg_launch_ms": avg_s * 1e3, "launches": gemm_cnt,
                          "note": "int8 TOP/s: 36 limb pairs x 2 x rows x c x 2l per launch"},
