@@ -91,23 +91,27 @@ class Aby3MatmulJob:
             off = self.row0 * self.l
             ctx.call("aby3_share_local", self.X if j == 0 else None, self.rows * self.l, sn, off, sp, off, self.RX[j])
             ctx.call("aby3_share_local", self.Y if j == 0 else None, n2y, sn, n2x, sp, n2x, self.RY[j])
+        works = []
         for j in range(3):
             nx, pv = (j + 1) % 3, (j + 2) % 3
             sn, sp = pair_seed(j, nx), pair_seed(j, pv)
             ctx.call("aby3_matmul_local_rows", self.RX[j], self.RX[nx], self.RY[j], self.RY[nx], self.rows, self.l,
                      self.c, self.row0, sn, pm, sp, pm, self.Z0[j])
-        if self.world > 1:
-            import torch.distributed as dist
-            for j in range(3):  # the message party j hands to the messenger: all row-blocks of Z0
+            if self.world > 1:
+                # the message party j hands to the messenger is all row-blocks of its Z0: one all-gather per party,
+                # started as soon as the block exists so that it travels over xGMI while the next party's product runs
+                import torch.distributed as dist
                 if self.host_gather:  # rehearsal without RCCL (gloo): through host memory
                     parts = [self.torch.empty(self.Z0[j].numel(), dtype=self.torch.int64) for _ in range(self.world)]
                     dist.all_gather(parts, self.Z0[j].cpu())
                     self.Zfull[j].copy_(self.torch.cat(parts))
                 else:
-                    dist.all_gather_into_tensor(self.Zfull[j], self.Z0[j])
+                    works.append(dist.all_gather_into_tensor(self.Zfull[j], self.Z0[j], async_op=True))
         for j in range(3):
             ctx.call("aby3_reveal3", self.Z0[(j + 2) % 3], self.Z0[j], self.Z0[(j + 1) % 3], self.Zplain[j],
                      self.rows * self.c)
+        for w in works:  # the step is over when every message is complete
+            w.wait()
 
     def ring_ops_per_step(self):
         return 3 * 3 * 2 * self.rows_total * self.l * self.c
