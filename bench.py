@@ -56,13 +56,13 @@ def prof_read(ctx, name):
 
 
 class Aby3MatmulJob:
-    def __init__(self, ctx, torch, dev, n, rank, world, host_gather=False):
+    def __init__(self, ctx, torch, dev, n, rank, world, host_gather=False, rows=None):
         self.ctx, self.torch, self.n, self.rank, self.world = ctx, torch, n, rank, world
         self.host_gather = host_gather
-        self.rows, self.l, self.c = n, n, n
-        self.rows_total = n * world
-        self.row0, rows = matmul_row_block(self.rows_total, world, rank)
-        assert rows == n
+        self.rows, self.l, self.c = rows or n, n, n
+        self.rows_total = self.rows * world
+        self.row0, rows_here = matmul_row_block(self.rows_total, world, rank)
+        assert rows_here == self.rows
         self.plan = aby3_matmul_pop_plan(self.rows_total, self.l, self.c)
         i64 = torch.int64
         e = lambda k: torch.empty(k, dtype=i64, device=dev)
@@ -294,6 +294,8 @@ def main():
     ap.add_argument("--no-bitwise", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="development only: skip the result check")
     ap.add_argument("--bitwise-log2n", type=int, default=24, help="elements of the privateCompare / msb / ReLU runs")
+    ap.add_argument("--rows", type=int, default=0, help="rows of X per GPU when different from --size (a row block "
+                    "of a larger product, e.g. --size 16384 --rows 2048 = one GPU's share of the 16384^2 configuration)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearsal of the multi-rank path on fewer GPUs than ranks (gathers through the host)")
     args = ap.parse_args()
@@ -319,7 +321,7 @@ def main():
     ctx = Context(dev_index)
     ctx.call("set_stream", torch.cuda.current_stream().cuda_stream)
 
-    job = Aby3MatmulJob(ctx, torch, dev, args.size, rank, world, host_gather=args.dist_backend == "gloo")
+    job = Aby3MatmulJob(ctx, torch, dev, args.size, rank, world, host_gather=args.dist_backend == "gloo", rows=args.rows or None)
 
     def barrier():
         if dist is not None:
@@ -349,9 +351,10 @@ def main():
         value = job.ring_ops_per_step() * args.steps / dt / 1e9
         # dominant kernel: the int8-limb MFMA GEMM.  Algorithmic work per launch: 36 limb pairs x 2 ops x
         # rows x c x K with K = 2l (the two ring products X0*(Y0+Y1) and X1*Y0 concatenated along K)
-        ops_per_launch = 36 * 2 * job.rows * job.c * (2 * job.l)
+        # (products with 2l > 8192 run as several K-chunk launches: count the work per product, not per launch)
+        ops_per_product = 36 * 2 * job.rows * job.c * (2 * job.l)
         avg_s = gemm_ms / gemm_cnt * 1e-3
-        achieved = ops_per_launch / avg_s / 1e12
+        achieved = ops_per_product * 3 * args.steps / (gemm_ms * 1e-3) / 1e12
         res = {
             "metric": "Z_2^64 share-matmul Gop/s + MSB/privateCompare elems/sec at 1/2/4/8 GPUs",
             "value": value, "unit": "Gop/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -365,7 +368,7 @@ def main():
                          "unit": "TFLOP/s", "frac": achieved / INT8_PEAK_TOPS, "traffic": measured_traffic(args.size, world),
                          "traffic_unit": "bytes per launch (profiles/r1_pmc_summary.json)",
                          "avg_launch_ms": avg_s * 1e3, "launches": gemm_cnt,
-                         "note": "int8 TOP/s: 36 limb pairs x 2 x rows x c x 2l per launch"},
+                         "note": "int8 TOP/s: 36 limb pairs x 2 x rows x c x 2l per product, over the summed launch time"},
             "kernel_ms_per_step": breakdown,
         }
         if world == 1 and not args.no_bitwise:
