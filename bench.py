@@ -28,7 +28,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-from mpc_amd.sharding import aby3_matmul_pop_plan, matmul_row_block  # noqa: E402
+from mpc_amd.sharding import aby3_matmul_pop_plan, matmul_row_block, split_range  # noqa: E402
 
 KEY01, KEY12, KEY20, KEYS = 0xAB01, 0xBC12, 0xCA20, 0xF0
 INT8_PEAK_TOPS = 5033.0  # 256 CU x 4 SIMD x 2048 int8 op/clk x 2.4 GHz (2x the 2.5 PF bf16 dense peak)
@@ -116,6 +116,12 @@ class Aby3MatmulJob:
     def ring_ops_per_step(self):
         return 3 * 3 * 2 * self.rows_total * self.l * self.c
 
+    def shape_only(self):
+        """The sizes without the device buffers (for the report after the buffers have been released)."""
+        o = object.__new__(Aby3MatmulJob)
+        o.rows, o.l, o.c, o.rows_total = self.rows, self.l, self.c, self.rows_total
+        return o
+
     def verify(self):
         """All parties reveal the same Z, and sampled entries equal the exact big-integer dot products."""
         t = self.torch
@@ -184,25 +190,37 @@ def _timed(torch, fn, reps=1):
     return (time.perf_counter() - t0) / reps, r
 
 
-def bitwise_rates(ctx, torch, dev, log2n=24):
-    """Secondary metrics, elements / s on one GPU with every buffer resident in HBM:
+def bitwise_rates(ctx, torch, dev, log2n=24, rank=0, world=1):
+    """Secondary metrics, elements / s with every buffer resident in HBM (this rank's element range; merged over
+    the ranks by merge_bitwise):
       * privateCompare, party role and helper role, as kernels (config 3's n = 2^24);
       * the whole SecureNN msb protocol (shareConvert + msb_L_1, all three roles played on this GPU, messages
         handed over as device pointers) and its per-segment device time;
       * the ABY3 ReLU chain add_prepare -> msb -> bit_inject -> subtract, all three parties on this GPU.
     "cold" regenerates the int_buff-derived random bytes inside the call; "warm" reads them from the device
-    cache, which is what the reference does after its constructor has filled int_buff."""
+    cache, which is what the reference does after its constructor has filled int_buff.
+
+    With several ranks every rank works on a contiguous element range (n_total, i0, n) of one vector.  The SecureNN
+    items split a vector of 2^log2n elements (its buffer offsets reach 256 * n_total words of a serial generator,
+    and walking those once per rank is set-up time that would dominate this script if n_total grew with the ranks);
+    the ABY3 chain, which only pops, gives every rank 2^log2n elements of a vector of world * 2^log2n."""
     import protocols as pr
     from backends import ResidentBackend
     be = ResidentBackend(ctx, torch, dev)
-    out = {"n": 1 << log2n}
-    n = 1 << log2n
     GiB = 1 << 30
+    nt = 1 << log2n                      # SecureNN: the whole vector
+    i0, n = split_range(nt, world, rank)  # ... and this rank's range of it
+    out = {"n": nt, "n_this_rank": n}
+    counts = {}                           # elements behind every *_elems_per_s entry (for the merge over ranks)
+
+    def rate(key, elems, dt):
+        out[key] = elems / dt
+        counts[key] = elems
 
     # ---- privateCompare kernels
     t0 = time.perf_counter()
-    ctx.call("prg_ckpt_build", KEY01, 0, 0, 128 * n)
-    ctx.call("prg_ckpt_build", KEYS, 0, 0, 67 * n + 64)
+    ctx.call("prg_ckpt_build", KEY01, 0, 0, 128 * nt)
+    ctx.call("prg_ckpt_build", KEYS, 0, 0, 67 * nt + 64)
     out["ckpt_build_s"] = round(time.perf_counter() - t0, 2)
     xb = torch.randint(0, 67, (64 * n,), dtype=torch.int16, device=dev)
     beta = torch.randint(0, 2, (n,), dtype=torch.int8, device=dev)
@@ -213,33 +231,28 @@ def bitwise_rates(ctx, torch, dev, log2n=24):
     b2 = torch.empty(n, dtype=torch.int8, device=dev)
     for label, cap in (("cold", 0), ("warm", 8 * GiB)):
         ctx.call("set_rand_cache", cap)
-        ctx.call("snn_pc_party", 0, xb, beta, r, n, 0, n, KEY01, d0)
-        ctx.call("snn_pc_party", 1, xb, beta, r, n, 0, n, KEY01, d1)
+        ctx.call("snn_pc_party", 0, xb, beta, r, nt, i0, n, KEY01, d0)
+        ctx.call("snn_pc_party", 1, xb, beta, r, nt, i0, n, KEY01, d1)
         ctx.call("profile", 1)
-        dt, _ = _timed(torch, lambda: ctx.call("snn_pc_party", 0, xb, beta, r, n, 0, n, KEY01, d0), reps=3)
+        dt, _ = _timed(torch, lambda: ctx.call("snn_pc_party", 0, xb, beta, r, nt, i0, n, KEY01, d0), reps=3)
         ms, cnt = prof_read(ctx, "pc_party")
         msp, _ = prof_read(ctx, "prg_fill")
         ctx.call("profile", 0)
-        out[f"pc_party_{label}_elems_per_s"] = n / dt
+        rate(f"pc_party_{label}_elems_per_s", n, dt)
         out[f"pc_party_{label}_kernel_ms"] = round(ms / cnt, 3)
         out[f"pc_party_{label}_prg_ms"] = round(msp / 3, 3)
-    # 265 B/elem of protocol data + the 64 cached s bytes (u is only read when beta = 1 and r = -1)
-    out["pc_party_warm_GBps"] = (265.0 + 64.0) * out["pc_party_warm_elems_per_s"] / 1e9
-    out["pc_party_warm_hbm_frac"] = out["pc_party_warm_GBps"] / HBM_PEAK_GBS
     dt, _ = _timed(torch, lambda: ctx.call("snn_pc_helper", d0, d1, n, b2), reps=3)
-    out["pc_helper_elems_per_s"] = n / dt
-    out["pc_helper_GBps"] = 257.0 * n / dt / 1e9
-    out["pc_helper_hbm_frac"] = out["pc_helper_GBps"] / HBM_PEAK_GBS
+    rate("pc_helper_elems_per_s", n, dt)
     del xb, d0, d1, b2, beta, r
 
     # ---- SecureNN msb, whole protocol (test/test_securenn.cpp:283-308: a = pop_int64() / 2)
     a = torch.empty(n, dtype=torch.int64, device=dev)
-    ctx.call("prg_fill_pop", 22, 0, 0, n, a)
+    ctx.call("prg_fill_pop", 22, 0, i0, n, a)
     a = torch.div(a, 2, rounding_mode="trunc")
     aD = ctx.wrap(a, np.int64)
 
     def snn_msb():
-        w = pr.World(be, record=False)
+        w = pr.World(be, record=False, n_total=nt, i0=i0)
         As = pr.snn_share(w, aD, n)
         return pr.snn_msb(w, As[:2])
 
@@ -250,7 +263,7 @@ def bitwise_rates(ctx, torch, dev, log2n=24):
         dt, B = _timed(torch, snn_msb)
         seg = be.segment_ms()
         be.events = None
-        out[f"snn_msb_{label}_elems_per_s"] = n / dt
+        rate(f"snn_msb_{label}_elems_per_s", n, dt)
         out[f"snn_msb_{label}_ms"] = round(dt * 1e3, 3)
         out[f"snn_msb_{label}_segments_ms"] = {k: round(v, 3) for k, v in sorted(seg.items(), key=lambda kv: -kv[1])}
     got = torch.from_numpy(be.down(B[0])).to(dev) + torch.from_numpy(be.down(B[1])).to(dev)
@@ -258,12 +271,15 @@ def bitwise_rates(ctx, torch, dev, log2n=24):
     del B, got
 
     # ---- ABY3 ReLU chain (test/test_ABY3.cpp:196-214, benchmark/benchmark1.cpp:69-74)
+    n = 1 << log2n  # ABY3: every rank's range
+    nt, i0 = n * world, n * rank
+    out["aby3_relu_n"] = nt
     x = torch.empty(n, dtype=torch.int64, device=dev)
-    ctx.call("prg_fill_pop", 21, 0, 0, n, x)
+    ctx.call("prg_fill_pop", 21, 0, i0, n, x)
     xD = ctx.wrap(x, np.int64)
 
     def aby3_relu():
-        w = pr.World(be, record=False)
+        w = pr.World(be, record=False, n_total=nt, i0=i0)
         Xs = pr.aby3_share(w, xD, n)
         Gs, Ps = pr.aby3_add_prepare(w, Xs)
         Zb = pr.aby3_msb(w, Gs, Ps)
@@ -275,12 +291,36 @@ def bitwise_rates(ctx, torch, dev, log2n=24):
     dt, R = _timed(torch, aby3_relu)
     seg = be.segment_ms()
     be.events = None
-    out["aby3_relu_elems_per_s"] = n / dt
+    rate("aby3_relu_elems_per_s", n, dt)
     out["aby3_relu_ms"] = round(dt * 1e3, 3)
     out["aby3_relu_segments_ms"] = {k: round(v, 3) for k, v in sorted(seg.items(), key=lambda kv: -kv[1])}
     got = sum(torch.from_numpy(be.down(R[j])).to(dev) for j in range(3))
     assert torch.equal(got, torch.clamp(x, min=0)), "ABY3 ReLU chain: revealed values differ from max(x, 0)"
     ctx.call("set_rand_cache", 4 * GiB)
+    out["_counts"] = counts
+    return out
+
+
+def merge_bitwise(per_rank):
+    """Whole-job element rates from the ranks' dictionaries: all elements of an item / the slowest rank's time.
+    Millisecond entries are rank 0's."""
+    errs = [d["error"] for d in per_rank if "error" in d]
+    if errs:
+        return {"error": "; ".join(errs)}
+    out = dict(per_rank[0])
+    counts = out.pop("_counts")
+    out.pop("n_this_rank", None)
+    for key in counts:
+        slowest = max(d["_counts"][key] / d[key] for d in per_rank)
+        out[key] = sum(d["_counts"][key] for d in per_rank) / slowest
+    g = len(per_rank)
+    # per-GPU HBM rates: 265 B/elem of protocol data + the 64 cached s bytes (u is only read when beta = 1 and
+    # r = -1) for the party role, 257 B/elem for the helper role
+    out["pc_party_warm_GBps_per_gpu"] = (265.0 + 64.0) * out["pc_party_warm_elems_per_s"] / g / 1e9
+    out["pc_party_warm_hbm_frac"] = out["pc_party_warm_GBps_per_gpu"] / HBM_PEAK_GBS
+    out["pc_helper_GBps_per_gpu"] = 257.0 * out["pc_helper_elems_per_s"] / g / 1e9
+    out["pc_helper_hbm_frac"] = out["pc_helper_GBps_per_gpu"] / HBM_PEAK_GBS
+    out["ranks"] = g
     return out
 
 
@@ -347,6 +387,18 @@ def main():
     if not args.no_verify:
         job.verify()
 
+    bitwise = None
+    if not args.no_bitwise:
+        job = job.shape_only()  # frees the matmul operands before the element-wise runs allocate theirs
+        torch.cuda.empty_cache()
+        try:
+            mine = bitwise_rates(ctx, torch, dev, args.bitwise_log2n, rank, world)
+        except Exception as ex:  # secondary metric must not hide the headline number
+            mine = {"error": f"rank {rank}: {ex}"}
+        bitwise = [mine]
+        if dist is not None:  # no collective inside bitwise_rates: a rank that failed still arrives here
+            bitwise = [None] * world
+            dist.all_gather_object(bitwise, mine)
     if rank == 0:
         value = job.ring_ops_per_step() * args.steps / dt / 1e9
         # dominant kernel: the int8-limb MFMA GEMM.  Algorithmic work per launch: 36 limb pairs x 2 ops x
@@ -371,11 +423,8 @@ def main():
                          "note": "int8 TOP/s: 36 limb pairs x 2 x rows x c x 2l per product, over the summed launch time"},
             "kernel_ms_per_step": breakdown,
         }
-        if world == 1 and not args.no_bitwise:
-            try:
-                res["bitwise"] = bitwise_rates(ctx, torch, dev, args.bitwise_log2n)
-            except Exception as ex:  # secondary metric must not hide the headline number
-                res["bitwise"] = {"error": str(ex)}
+        if bitwise is not None:
+            res["bitwise"] = merge_bitwise(bitwise)
         if world == 1 and not args.no_cpu:
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res), flush=True)

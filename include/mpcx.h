@@ -148,24 +148,28 @@ int mpcx_aby3_trunc_local(mpcx_ctx *ctx, int party, const int64_t *X0, const int
  *  P1: to_p0 = (M1_0^W12_0)[n]|(M1_1^W12_1)[n]            to_p2 = W01_b[n]|(M1_0^W10_0)[n]|(M1_1^W10_1)[n]
  *  P2: to_p0 = W12_b[n]                                   to_p1 = W02_b[n]
  * pop01/pop20/pop12 = the caller's pop index into that stream when bit_inject starts (the call consumes
- * 6n words of s01 and 3n of s20 on P0; 6n of s01, 3n of s12 on P1; 3n of s20, 3n of s12 on P2). */
-int mpcx_aby3_bit_inject_p0_pre(mpcx_ctx *ctx, const int64_t *A0, const int8_t *B0, const int8_t *B1, uint64_t n,
-                                uint64_t seed01, uint64_t pop01, uint64_t seed20, uint64_t pop20, int64_t *to_p1,
-                                int64_t *to_p2);
-int mpcx_aby3_bit_inject_p0_post(mpcx_ctx *ctx, const int8_t *B0, uint64_t n, uint64_t seed01, uint64_t pop01,
-                                 uint64_t seed20, uint64_t pop20, const int64_t *from_p1, const int64_t *from_p2,
-                                 int64_t *C0, int64_t *C1);
+ * 6n words of s01 and 3n of s20 on P0; 6n of s01, 3n of s12 on P1; 3n of s20, 3n of s12 on P2).
+ * A call handles elements [i0, i0+n) of a vector of n_total elements (one GPU's range; n_total = n, i0 = 0 for
+ * the whole vector): the stream sections are indexed per whole vector (:539-558), the message sections above
+ * have n entries each, so the ranges of a section concatenate to the whole vector's section. */
+int mpcx_aby3_bit_inject_p0_pre(mpcx_ctx *ctx, const int64_t *A0, const int8_t *B0, const int8_t *B1, uint64_t n_total,
+                                uint64_t i0, uint64_t n, uint64_t seed01, uint64_t pop01, uint64_t seed20,
+                                uint64_t pop20, int64_t *to_p1, int64_t *to_p2);
+int mpcx_aby3_bit_inject_p0_post(mpcx_ctx *ctx, const int8_t *B0, uint64_t n_total, uint64_t i0, uint64_t n,
+                                 uint64_t seed01, uint64_t pop01, uint64_t seed20, uint64_t pop20,
+                                 const int64_t *from_p1, const int64_t *from_p2, int64_t *C0, int64_t *C1);
 int mpcx_aby3_bit_inject_p1_pre(mpcx_ctx *ctx, const int64_t *A0, const int64_t *A1, const int8_t *B0,
-                                const int8_t *B1, uint64_t n, uint64_t seed01, uint64_t pop01, uint64_t seed12,
-                                uint64_t pop12, int64_t *to_p0, int64_t *to_p2);
-int mpcx_aby3_bit_inject_p1_post(mpcx_ctx *ctx, const int8_t *B1, uint64_t n, uint64_t seed01, uint64_t pop01,
-                                 uint64_t seed12, uint64_t pop12, const int64_t *from_p0, const int64_t *from_p2,
-                                 int64_t *C0, int64_t *C1);
-int mpcx_aby3_bit_inject_p2_pre(mpcx_ctx *ctx, const int8_t *B0, const int8_t *B1, uint64_t n, uint64_t seed20,
-                                uint64_t pop20, uint64_t seed12, uint64_t pop12, int64_t *to_p0, int64_t *to_p1);
-int mpcx_aby3_bit_inject_p2_post(mpcx_ctx *ctx, const int8_t *B0, const int8_t *B1, uint64_t n, uint64_t seed20,
-                                 uint64_t pop20, uint64_t seed12, uint64_t pop12, const int64_t *from_p0,
-                                 const int64_t *from_p1, int64_t *C0, int64_t *C1);
+                                const int8_t *B1, uint64_t n_total, uint64_t i0, uint64_t n, uint64_t seed01,
+                                uint64_t pop01, uint64_t seed12, uint64_t pop12, int64_t *to_p0, int64_t *to_p2);
+int mpcx_aby3_bit_inject_p1_post(mpcx_ctx *ctx, const int8_t *B1, uint64_t n_total, uint64_t i0, uint64_t n,
+                                 uint64_t seed01, uint64_t pop01, uint64_t seed12, uint64_t pop12,
+                                 const int64_t *from_p0, const int64_t *from_p2, int64_t *C0, int64_t *C1);
+int mpcx_aby3_bit_inject_p2_pre(mpcx_ctx *ctx, const int8_t *B0, const int8_t *B1, uint64_t n_total, uint64_t i0,
+                                uint64_t n, uint64_t seed20, uint64_t pop20, uint64_t seed12, uint64_t pop12,
+                                int64_t *to_p0, int64_t *to_p1);
+int mpcx_aby3_bit_inject_p2_post(mpcx_ctx *ctx, const int8_t *B0, const int8_t *B1, uint64_t n_total, uint64_t i0,
+                                 uint64_t n, uint64_t seed20, uint64_t pop20, uint64_t seed12, uint64_t pop12,
+                                 const int64_t *from_p0, const int64_t *from_p1, int64_t *C0, int64_t *C1);
 
 /* ---- SecurennEngine (mpc_engine/SecurennEngine.cpp) ---- */
 /* share (:318-334): party 0: -pop(s01); party 1: X + pop(s01); party 2: zeros */

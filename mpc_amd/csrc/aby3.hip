@@ -381,16 +381,32 @@ int mpcx_aby3_trunc_local(mpcx_ctx *ctx, int party, const int64_t *X0, const int
 
 // ---- bit_inject: the PRG words of the call are regenerated into scratch (s01: 6n or 3n words, other
 // stream: 3n words), then one streaming pass forms the messages / the output shares.
-int mpcx_aby3_bit_inject_p0_pre(mpcx_ctx *ctx, const int64_t *A0, const int8_t *B0, const int8_t *B1, uint64_t n,
-                                uint64_t seed01, uint64_t pop01, uint64_t seed20, uint64_t pop20, int64_t *to_p1,
-                                int64_t *to_p2) {
+// A call works on elements [i0, i0 + n) of a vector of n_total elements.  The reference lays the words of a
+// stream out per whole vector (ABY3Engine.cpp:539-558): C[n_total], then n_total (W_0, W_1) pairs, and on s01
+// the same again for the second OT.  The scratch copy keeps that order with sections of n.
+} // extern "C"
+// sections C | W pairs of one OT, `base` = stream word of C[0] of the whole vector
+static int bi_fill_ot(mpcx_ctx *ctx, u64 seed, u64 base, u64 n_total, u64 i0, u64 n, u64 *dst) {
+    if (n == n_total) return prg_fill_words(ctx, seed, 0, base, 3 * n, 1, (i64 *)dst, nullptr);
+    MPCX_TRY(prg_fill_words(ctx, seed, 0, base + i0, n, 1, (i64 *)dst, nullptr));
+    return prg_fill_words(ctx, seed, 0, base + n_total + 2 * i0, 2 * n, 1, (i64 *)(dst + n), nullptr);
+}
+#define BI_RANGE_CHECK(name)                                                                                           \
+    MPCX_REQUIRE(i0 <= n_total && n <= n_total - i0, name ": elements [%llu, +%llu) outside a vector of %llu",          \
+                 (unsigned long long)i0, (unsigned long long)n, (unsigned long long)n_total)
+extern "C" {
+int mpcx_aby3_bit_inject_p0_pre(mpcx_ctx *ctx, const int64_t *A0, const int8_t *B0, const int8_t *B1, uint64_t n_total,
+                                uint64_t i0, uint64_t n, uint64_t seed01, uint64_t pop01, uint64_t seed20,
+                                uint64_t pop20, int64_t *to_p1, int64_t *to_p2) {
+    BI_RANGE_CHECK("mpcx_aby3_bit_inject_p0_pre");
     if (n == 0) return 0;
     MPCX_REQUIRE(A0 && B0 && B1 && to_p1 && to_p2, "mpcx_aby3_bit_inject_p0_pre: NULL pointer");
     void *ws;
     MPCX_TRY(mpcx_ws(ctx, 72 * n, &ws));
     u64 *s01 = (u64 *)ws, *s20 = s01 + 6 * n;
-    MPCX_TRY(prg_fill_words(ctx, seed01, 0, PRG_POP_T0 + pop01, 6 * n, 1, (i64 *)s01, nullptr));
-    MPCX_TRY(prg_fill_words(ctx, seed20, 0, PRG_POP_T0 + pop20, 3 * n, 1, (i64 *)s20, nullptr));
+    MPCX_TRY(bi_fill_ot(ctx, seed01, PRG_POP_T0 + pop01, n_total, i0, n, s01));
+    MPCX_TRY(bi_fill_ot(ctx, seed01, PRG_POP_T0 + pop01 + 3 * n_total, n_total, i0, n, s01 + 3 * n));
+    MPCX_TRY(bi_fill_ot(ctx, seed20, PRG_POP_T0 + pop20, n_total, i0, n, s20));
     u64 *m1 = (u64 *)to_p1, *m2 = (u64 *)to_p2;
     return ew_launch(ctx, n, [=] __device__(u64 i) {
         const u64 cc = s01[i] + s20[i];
@@ -404,17 +420,18 @@ int mpcx_aby3_bit_inject_p0_pre(mpcx_ctx *ctx, const int64_t *A0, const int8_t *
         m2[2 * n + i] = B0[i] == 1 ? s01[4 * n + 2 * i + 1] : s01[4 * n + 2 * i]; // :603
     });
 }
-int mpcx_aby3_bit_inject_p0_post(mpcx_ctx *ctx, const int8_t *B0, uint64_t n, uint64_t seed01, uint64_t pop01,
-                                 uint64_t seed20, uint64_t pop20, const int64_t *from_p1, const int64_t *from_p2,
-                                 int64_t *C0, int64_t *C1) {
+int mpcx_aby3_bit_inject_p0_post(mpcx_ctx *ctx, const int8_t *B0, uint64_t n_total, uint64_t i0, uint64_t n,
+                                 uint64_t seed01, uint64_t pop01, uint64_t seed20, uint64_t pop20,
+                                 const int64_t *from_p1, const int64_t *from_p2, int64_t *C0, int64_t *C1) {
+    BI_RANGE_CHECK("mpcx_aby3_bit_inject_p0_post");
     if (n == 0) return 0;
     MPCX_REQUIRE(B0 && from_p1 && from_p2 && C0 && C1, "mpcx_aby3_bit_inject_p0_post: NULL pointer");
     void *ws;
     MPCX_TRY(mpcx_ws(ctx, 24 * n, &ws));
     u64 *c01 = (u64 *)ws, *c10 = c01 + n, *c02 = c10 + n;
-    MPCX_TRY(prg_fill_words(ctx, seed01, 0, PRG_POP_T0 + pop01, n, 1, (i64 *)c01, nullptr));
-    MPCX_TRY(prg_fill_words(ctx, seed01, 0, PRG_POP_T0 + pop01 + 3 * n, n, 1, (i64 *)c10, nullptr));
-    MPCX_TRY(prg_fill_words(ctx, seed20, 0, PRG_POP_T0 + pop20, n, 1, (i64 *)c02, nullptr));
+    MPCX_TRY(prg_fill_words(ctx, seed01, 0, PRG_POP_T0 + pop01 + i0, n, 1, (i64 *)c01, nullptr));
+    MPCX_TRY(prg_fill_words(ctx, seed01, 0, PRG_POP_T0 + pop01 + 3 * n_total + i0, n, 1, (i64 *)c10, nullptr));
+    MPCX_TRY(prg_fill_words(ctx, seed20, 0, PRG_POP_T0 + pop20 + i0, n, 1, (i64 *)c02, nullptr));
     const u64 *f1 = (const u64 *)from_p1, *f2 = (const u64 *)from_p2;
     u64 *o0 = (u64 *)C0, *o1 = (u64 *)C1;
     return ew_launch(ctx, n, [=] __device__(u64 i) {
@@ -424,15 +441,17 @@ int mpcx_aby3_bit_inject_p0_post(mpcx_ctx *ctx, const int8_t *B0, uint64_t n, ui
     });
 }
 int mpcx_aby3_bit_inject_p1_pre(mpcx_ctx *ctx, const int64_t *A0, const int64_t *A1, const int8_t *B0,
-                                const int8_t *B1, uint64_t n, uint64_t seed01, uint64_t pop01, uint64_t seed12,
-                                uint64_t pop12, int64_t *to_p0, int64_t *to_p2) {
+                                const int8_t *B1, uint64_t n_total, uint64_t i0, uint64_t n, uint64_t seed01,
+                                uint64_t pop01, uint64_t seed12, uint64_t pop12, int64_t *to_p0, int64_t *to_p2) {
+    BI_RANGE_CHECK("mpcx_aby3_bit_inject_p1_pre");
     if (n == 0) return 0;
     MPCX_REQUIRE(A0 && A1 && B0 && B1 && to_p0 && to_p2, "mpcx_aby3_bit_inject_p1_pre: NULL pointer");
     void *ws;
     MPCX_TRY(mpcx_ws(ctx, 72 * n, &ws));
     u64 *s01 = (u64 *)ws, *s12 = s01 + 6 * n;
-    MPCX_TRY(prg_fill_words(ctx, seed01, 0, PRG_POP_T0 + pop01, 6 * n, 1, (i64 *)s01, nullptr));
-    MPCX_TRY(prg_fill_words(ctx, seed12, 0, PRG_POP_T0 + pop12, 3 * n, 1, (i64 *)s12, nullptr));
+    MPCX_TRY(bi_fill_ot(ctx, seed01, PRG_POP_T0 + pop01, n_total, i0, n, s01));
+    MPCX_TRY(bi_fill_ot(ctx, seed01, PRG_POP_T0 + pop01 + 3 * n_total, n_total, i0, n, s01 + 3 * n));
+    MPCX_TRY(bi_fill_ot(ctx, seed12, PRG_POP_T0 + pop12, n_total, i0, n, s12));
     u64 *m0 = (u64 *)to_p0, *m2 = (u64 *)to_p2;
     return ew_launch(ctx, n, [=] __device__(u64 i) {
         const u64 cc = s01[3 * n + i] + s12[i]; // C10 + C12
@@ -446,17 +465,18 @@ int mpcx_aby3_bit_inject_p1_pre(mpcx_ctx *ctx, const int64_t *A0, const int64_t 
         m0[n + i] = M1 ^ s12[n + 2 * i + 1];
     });
 }
-int mpcx_aby3_bit_inject_p1_post(mpcx_ctx *ctx, const int8_t *B1, uint64_t n, uint64_t seed01, uint64_t pop01,
-                                 uint64_t seed12, uint64_t pop12, const int64_t *from_p0, const int64_t *from_p2,
-                                 int64_t *C0, int64_t *C1) {
+int mpcx_aby3_bit_inject_p1_post(mpcx_ctx *ctx, const int8_t *B1, uint64_t n_total, uint64_t i0, uint64_t n,
+                                 uint64_t seed01, uint64_t pop01, uint64_t seed12, uint64_t pop12,
+                                 const int64_t *from_p0, const int64_t *from_p2, int64_t *C0, int64_t *C1) {
+    BI_RANGE_CHECK("mpcx_aby3_bit_inject_p1_post");
     if (n == 0) return 0;
     MPCX_REQUIRE(B1 && from_p0 && from_p2 && C0 && C1, "mpcx_aby3_bit_inject_p1_post: NULL pointer");
     void *ws;
     MPCX_TRY(mpcx_ws(ctx, 24 * n, &ws));
     u64 *c01 = (u64 *)ws, *c10 = c01 + n, *c12 = c10 + n;
-    MPCX_TRY(prg_fill_words(ctx, seed01, 0, PRG_POP_T0 + pop01, n, 1, (i64 *)c01, nullptr));
-    MPCX_TRY(prg_fill_words(ctx, seed01, 0, PRG_POP_T0 + pop01 + 3 * n, n, 1, (i64 *)c10, nullptr));
-    MPCX_TRY(prg_fill_words(ctx, seed12, 0, PRG_POP_T0 + pop12, n, 1, (i64 *)c12, nullptr));
+    MPCX_TRY(prg_fill_words(ctx, seed01, 0, PRG_POP_T0 + pop01 + i0, n, 1, (i64 *)c01, nullptr));
+    MPCX_TRY(prg_fill_words(ctx, seed01, 0, PRG_POP_T0 + pop01 + 3 * n_total + i0, n, 1, (i64 *)c10, nullptr));
+    MPCX_TRY(prg_fill_words(ctx, seed12, 0, PRG_POP_T0 + pop12 + i0, n, 1, (i64 *)c12, nullptr));
     const u64 *f0 = (const u64 *)from_p0, *f2 = (const u64 *)from_p2;
     u64 *o0 = (u64 *)C0, *o1 = (u64 *)C1;
     return ew_launch(ctx, n, [=] __device__(u64 i) {
@@ -465,31 +485,34 @@ int mpcx_aby3_bit_inject_p1_post(mpcx_ctx *ctx, const int8_t *B1, uint64_t n, ui
         o1[i] = a0 + c12[i];                                      // A0j[1] + A12j[1]
     });
 }
-int mpcx_aby3_bit_inject_p2_pre(mpcx_ctx *ctx, const int8_t *B0, const int8_t *B1, uint64_t n, uint64_t seed20,
-                                uint64_t pop20, uint64_t seed12, uint64_t pop12, int64_t *to_p0, int64_t *to_p1) {
+int mpcx_aby3_bit_inject_p2_pre(mpcx_ctx *ctx, const int8_t *B0, const int8_t *B1, uint64_t n_total, uint64_t i0,
+                                uint64_t n, uint64_t seed20, uint64_t pop20, uint64_t seed12, uint64_t pop12,
+                                int64_t *to_p0, int64_t *to_p1) {
+    BI_RANGE_CHECK("mpcx_aby3_bit_inject_p2_pre");
     if (n == 0) return 0;
     MPCX_REQUIRE(B0 && B1 && to_p0 && to_p1, "mpcx_aby3_bit_inject_p2_pre: NULL pointer");
     void *ws;
     MPCX_TRY(mpcx_ws(ctx, 32 * n, &ws));
     u64 *w02 = (u64 *)ws, *w12 = w02 + 2 * n;
-    MPCX_TRY(prg_fill_words(ctx, seed20, 0, PRG_POP_T0 + pop20 + n, 2 * n, 1, (i64 *)w02, nullptr));
-    MPCX_TRY(prg_fill_words(ctx, seed12, 0, PRG_POP_T0 + pop12 + n, 2 * n, 1, (i64 *)w12, nullptr));
+    MPCX_TRY(prg_fill_words(ctx, seed20, 0, PRG_POP_T0 + pop20 + n_total + 2 * i0, 2 * n, 1, (i64 *)w02, nullptr));
+    MPCX_TRY(prg_fill_words(ctx, seed12, 0, PRG_POP_T0 + pop12 + n_total + 2 * i0, 2 * n, 1, (i64 *)w12, nullptr));
     u64 *m0 = (u64 *)to_p0, *m1 = (u64 *)to_p1;
     return ew_launch(ctx, n, [=] __device__(u64 i) {
         m1[i] = B0[i] == 1 ? w02[2 * i + 1] : w02[2 * i]; // :888
         m0[i] = B1[i] == 1 ? w12[2 * i + 1] : w12[2 * i]; // :922
     });
 }
-int mpcx_aby3_bit_inject_p2_post(mpcx_ctx *ctx, const int8_t *B0, const int8_t *B1, uint64_t n, uint64_t seed20,
-                                 uint64_t pop20, uint64_t seed12, uint64_t pop12, const int64_t *from_p0,
-                                 const int64_t *from_p1, int64_t *C0, int64_t *C1) {
+int mpcx_aby3_bit_inject_p2_post(mpcx_ctx *ctx, const int8_t *B0, const int8_t *B1, uint64_t n_total, uint64_t i0,
+                                 uint64_t n, uint64_t seed20, uint64_t pop20, uint64_t seed12, uint64_t pop12,
+                                 const int64_t *from_p0, const int64_t *from_p1, int64_t *C0, int64_t *C1) {
+    BI_RANGE_CHECK("mpcx_aby3_bit_inject_p2_post");
     if (n == 0) return 0;
     MPCX_REQUIRE(B0 && B1 && from_p0 && from_p1 && C0 && C1, "mpcx_aby3_bit_inject_p2_post: NULL pointer");
     void *ws;
     MPCX_TRY(mpcx_ws(ctx, 16 * n, &ws));
     u64 *c02 = (u64 *)ws, *c12 = c02 + n;
-    MPCX_TRY(prg_fill_words(ctx, seed20, 0, PRG_POP_T0 + pop20, n, 1, (i64 *)c02, nullptr));
-    MPCX_TRY(prg_fill_words(ctx, seed12, 0, PRG_POP_T0 + pop12, n, 1, (i64 *)c12, nullptr));
+    MPCX_TRY(prg_fill_words(ctx, seed20, 0, PRG_POP_T0 + pop20 + i0, n, 1, (i64 *)c02, nullptr));
+    MPCX_TRY(prg_fill_words(ctx, seed12, 0, PRG_POP_T0 + pop12 + i0, n, 1, (i64 *)c12, nullptr));
     const u64 *f0 = (const u64 *)from_p0, *f1 = (const u64 *)from_p1;
     u64 *o0 = (u64 *)C0, *o1 = (u64 *)C1;
     return ew_launch(ctx, n, [=] __device__(u64 i) {

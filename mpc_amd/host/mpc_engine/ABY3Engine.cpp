@@ -291,7 +291,7 @@ void ABY3Engine::bit_inject(const array<VecI64, 2> &Aj, const array<vecbool, 2> 
         PRgenerator &s01 = prgs[1], &s20 = prgs[2];
         const uint64_t pop01 = s01.pops, pop20 = s20.pops;
         Dev<int64_t> to1(gpu, 2 * n), to2(gpu, 3 * n), from1(gpu, 2 * n), from2(gpu, n);
-        GPU_OK(gpu, mpcx_aby3_bit_inject_p0_pre(gpu, a0, b0, b1, n, s01.init_seed, pop01, s20.init_seed, pop20, to1, to2));
+        GPU_OK(gpu, mpcx_aby3_bit_inject_p0_pre(gpu, a0, b0, b1, n, 0, n, s01.init_seed, pop01, s20.init_seed, pop20, to1, to2));
         s01.advance(gpu, 6 * n);
         s20.advance(gpu, 3 * n);
         to1.to_string(message_send[1]);
@@ -300,12 +300,12 @@ void ABY3Engine::bit_inject(const array<VecI64, 2> &Aj, const array<vecbool, 2> 
         assert(message_recv[1].size() == 2 * w && message_recv[2].size() == w);
         upload_string(from1, message_recv[1]);
         upload_string(from2, message_recv[2]);
-        GPU_OK(gpu, mpcx_aby3_bit_inject_p0_post(gpu, b0, n, s01.init_seed, pop01, s20.init_seed, pop20, from1, from2, c0, c1));
+        GPU_OK(gpu, mpcx_aby3_bit_inject_p0_post(gpu, b0, n, 0, n, s01.init_seed, pop01, s20.init_seed, pop20, from1, from2, c0, c1));
     } else if (party_id == 1) {
         PRgenerator &s01 = prgs[0], &s12 = prgs[2];
         const uint64_t pop01 = s01.pops, pop12 = s12.pops;
         Dev<int64_t> to0(gpu, 2 * n), to2(gpu, 3 * n), from0(gpu, 2 * n), from2(gpu, n);
-        GPU_OK(gpu, mpcx_aby3_bit_inject_p1_pre(gpu, a0, a1, b0, b1, n, s01.init_seed, pop01, s12.init_seed, pop12, to0, to2));
+        GPU_OK(gpu, mpcx_aby3_bit_inject_p1_pre(gpu, a0, a1, b0, b1, n, 0, n, s01.init_seed, pop01, s12.init_seed, pop12, to0, to2));
         s01.advance(gpu, 6 * n);
         s12.advance(gpu, 3 * n);
         to0.to_string(message_send[0]);
@@ -314,12 +314,12 @@ void ABY3Engine::bit_inject(const array<VecI64, 2> &Aj, const array<vecbool, 2> 
         assert(message_recv[0].size() == 2 * w && message_recv[2].size() == w);
         upload_string(from0, message_recv[0]);
         upload_string(from2, message_recv[2]);
-        GPU_OK(gpu, mpcx_aby3_bit_inject_p1_post(gpu, b1, n, s01.init_seed, pop01, s12.init_seed, pop12, from0, from2, c0, c1));
+        GPU_OK(gpu, mpcx_aby3_bit_inject_p1_post(gpu, b1, n, 0, n, s01.init_seed, pop01, s12.init_seed, pop12, from0, from2, c0, c1));
     } else {
         PRgenerator &s20 = prgs[0], &s12 = prgs[1];
         const uint64_t pop20 = s20.pops, pop12 = s12.pops;
         Dev<int64_t> to0(gpu, n), to1(gpu, n), from0(gpu, 3 * n), from1(gpu, 3 * n);
-        GPU_OK(gpu, mpcx_aby3_bit_inject_p2_pre(gpu, b0, b1, n, s20.init_seed, pop20, s12.init_seed, pop12, to0, to1));
+        GPU_OK(gpu, mpcx_aby3_bit_inject_p2_pre(gpu, b0, b1, n, 0, n, s20.init_seed, pop20, s12.init_seed, pop12, to0, to1));
         s20.advance(gpu, 3 * n);
         s12.advance(gpu, 3 * n);
         to0.to_string(message_send[0]);
@@ -328,7 +328,7 @@ void ABY3Engine::bit_inject(const array<VecI64, 2> &Aj, const array<vecbool, 2> 
         assert(message_recv[0].size() == 3 * w && message_recv[1].size() == 3 * w);
         upload_string(from0, message_recv[0]);
         upload_string(from1, message_recv[1]);
-        GPU_OK(gpu, mpcx_aby3_bit_inject_p2_post(gpu, b0, b1, n, s20.init_seed, pop20, s12.init_seed, pop12, from0, from1, c0, c1));
+        GPU_OK(gpu, mpcx_aby3_bit_inject_p2_post(gpu, b0, b1, n, 0, n, s20.init_seed, pop20, s12.init_seed, pop12, from0, from1, c0, c1));
     }
     Cj[0].resize(n);
     Cj[1].resize(n);

@@ -135,42 +135,48 @@ class OracleBackend:
         self.o.orc_aby3_trunc_local(party, _c(X0, np.int64), _c(X1, np.int64), X0.size, number, seed12, pop12, out)
         return out
 
-    def aby3_bit_inject_p0_pre(self, A0, B0, B1, seed01, pop01, seed20, pop20):
+    def aby3_bit_inject_p0_pre(self, A0, B0, B1, seed01, pop01, seed20, pop20, rng=None):
         n = A0.size
+        assert rng is None or tuple(rng) == (n, 0), "the CPU restatement handles whole vectors only"
         to1, to2 = i64(2 * n), i64(3 * n)
         self.o.orc_aby3_bit_inject_p0_pre(_c(A0, np.int64), _c(B0, np.int8), _c(B1, np.int8), n, seed01, pop01, seed20,
                                           pop20, to1, to2)
         return to1, to2
 
-    def aby3_bit_inject_p0_post(self, B0, seed01, pop01, seed20, pop20, from1, from2):
+    def aby3_bit_inject_p0_post(self, B0, seed01, pop01, seed20, pop20, from1, from2, rng=None):
         n = B0.size
+        assert rng is None or tuple(rng) == (n, 0), "the CPU restatement handles whole vectors only"
         C0, C1 = i64(n), i64(n)
         self.o.orc_aby3_bit_inject_p0_post(_c(B0, np.int8), n, seed01, pop01, seed20, pop20, _c(from1, np.int64),
                                            _c(from2, np.int64), C0, C1)
         return C0, C1
 
-    def aby3_bit_inject_p1_pre(self, A0, A1, B0, B1, seed01, pop01, seed12, pop12):
+    def aby3_bit_inject_p1_pre(self, A0, A1, B0, B1, seed01, pop01, seed12, pop12, rng=None):
         n = A0.size
+        assert rng is None or tuple(rng) == (n, 0), "the CPU restatement handles whole vectors only"
         to0, to2 = i64(2 * n), i64(3 * n)
         self.o.orc_aby3_bit_inject_p1_pre(_c(A0, np.int64), _c(A1, np.int64), _c(B0, np.int8), _c(B1, np.int8), n,
                                           seed01, pop01, seed12, pop12, to0, to2)
         return to0, to2
 
-    def aby3_bit_inject_p1_post(self, B1, seed01, pop01, seed12, pop12, from0, from2):
+    def aby3_bit_inject_p1_post(self, B1, seed01, pop01, seed12, pop12, from0, from2, rng=None):
         n = B1.size
+        assert rng is None or tuple(rng) == (n, 0), "the CPU restatement handles whole vectors only"
         C0, C1 = i64(n), i64(n)
         self.o.orc_aby3_bit_inject_p1_post(_c(B1, np.int8), n, seed01, pop01, seed12, pop12, _c(from0, np.int64),
                                            _c(from2, np.int64), C0, C1)
         return C0, C1
 
-    def aby3_bit_inject_p2_pre(self, B0, B1, seed20, pop20, seed12, pop12):
+    def aby3_bit_inject_p2_pre(self, B0, B1, seed20, pop20, seed12, pop12, rng=None):
         n = B0.size
+        assert rng is None or tuple(rng) == (n, 0), "the CPU restatement handles whole vectors only"
         to0, to1 = i64(n), i64(n)
         self.o.orc_aby3_bit_inject_p2_pre(_c(B0, np.int8), _c(B1, np.int8), n, seed20, pop20, seed12, pop12, to0, to1)
         return to0, to1
 
-    def aby3_bit_inject_p2_post(self, B0, B1, seed20, pop20, seed12, pop12, from0, from1):
+    def aby3_bit_inject_p2_post(self, B0, B1, seed20, pop20, seed12, pop12, from0, from1, rng=None):
         n = B0.size
+        assert rng is None or tuple(rng) == (n, 0), "the CPU restatement handles whole vectors only"
         C0, C1 = i64(n), i64(n)
         self.o.orc_aby3_bit_inject_p2_post(_c(B0, np.int8), _c(B1, np.int8), n, seed20, pop20, seed12, pop12,
                                            _c(from0, np.int64), _c(from1, np.int64), C0, C1)
@@ -437,34 +443,42 @@ class GpuBackend:
         return self._go("aby3_trunc_local", party, _c(X0, np.int64), _c(X1, np.int64), X0.size, number, seed12, pop12,
                         ("out", np.int64, X0.size))
 
-    def aby3_bit_inject_p0_pre(self, A0, B0, B1, seed01, pop01, seed20, pop20):
+    # bit_inject: rng = (n_total, i0) when the arrays are elements [i0, i0 + n) of a longer vector
+    def aby3_bit_inject_p0_pre(self, A0, B0, B1, seed01, pop01, seed20, pop20, rng=None):
         n = A0.size
-        return self._go("aby3_bit_inject_p0_pre", _c(A0, np.int64), _c(B0, np.int8), _c(B1, np.int8), n, seed01, pop01,
-                        seed20, pop20, ("out", np.int64, 2 * n), ("out", np.int64, 3 * n))
+        nt, i0 = rng or (n, 0)
+        return self._go("aby3_bit_inject_p0_pre", _c(A0, np.int64), _c(B0, np.int8), _c(B1, np.int8), nt, i0, n, seed01,
+                        pop01, seed20, pop20, ("out", np.int64, 2 * n), ("out", np.int64, 3 * n))
 
-    def aby3_bit_inject_p0_post(self, B0, seed01, pop01, seed20, pop20, from1, from2):
+    def aby3_bit_inject_p0_post(self, B0, seed01, pop01, seed20, pop20, from1, from2, rng=None):
         n = B0.size
-        return self._go("aby3_bit_inject_p0_post", _c(B0, np.int8), n, seed01, pop01, seed20, pop20,
+        nt, i0 = rng or (n, 0)
+        return self._go("aby3_bit_inject_p0_post", _c(B0, np.int8), nt, i0, n, seed01, pop01, seed20, pop20,
                         _c(from1, np.int64), _c(from2, np.int64), ("out", np.int64, n), ("out", np.int64, n))
 
-    def aby3_bit_inject_p1_pre(self, A0, A1, B0, B1, seed01, pop01, seed12, pop12):
+    def aby3_bit_inject_p1_pre(self, A0, A1, B0, B1, seed01, pop01, seed12, pop12, rng=None):
         n = A0.size
+        nt, i0 = rng or (n, 0)
         return self._go("aby3_bit_inject_p1_pre", _c(A0, np.int64), _c(A1, np.int64), _c(B0, np.int8), _c(B1, np.int8),
-                        n, seed01, pop01, seed12, pop12, ("out", np.int64, 2 * n), ("out", np.int64, 3 * n))
+                        nt, i0, n, seed01, pop01, seed12, pop12, ("out", np.int64, 2 * n), ("out", np.int64, 3 * n))
 
-    def aby3_bit_inject_p1_post(self, B1, seed01, pop01, seed12, pop12, from0, from2):
+    def aby3_bit_inject_p1_post(self, B1, seed01, pop01, seed12, pop12, from0, from2, rng=None):
         n = B1.size
-        return self._go("aby3_bit_inject_p1_post", _c(B1, np.int8), n, seed01, pop01, seed12, pop12,
+        nt, i0 = rng or (n, 0)
+        return self._go("aby3_bit_inject_p1_post", _c(B1, np.int8), nt, i0, n, seed01, pop01, seed12, pop12,
                         _c(from0, np.int64), _c(from2, np.int64), ("out", np.int64, n), ("out", np.int64, n))
 
-    def aby3_bit_inject_p2_pre(self, B0, B1, seed20, pop20, seed12, pop12):
+    def aby3_bit_inject_p2_pre(self, B0, B1, seed20, pop20, seed12, pop12, rng=None):
         n = B0.size
-        return self._go("aby3_bit_inject_p2_pre", _c(B0, np.int8), _c(B1, np.int8), n, seed20, pop20, seed12, pop12,
+        nt, i0 = rng or (n, 0)
+        return self._go("aby3_bit_inject_p2_pre", _c(B0, np.int8), _c(B1, np.int8), nt, i0, n, seed20, pop20, seed12, pop12,
                         ("out", np.int64, n), ("out", np.int64, n))
 
-    def aby3_bit_inject_p2_post(self, B0, B1, seed20, pop20, seed12, pop12, from0, from1):
+    def aby3_bit_inject_p2_post(self, B0, B1, seed20, pop20, seed12, pop12, from0, from1, rng=None):
         n = B0.size
-        return self._go("aby3_bit_inject_p2_post", _c(B0, np.int8), _c(B1, np.int8), n, seed20, pop20, seed12, pop12,
+        nt, i0 = rng or (n, 0)
+        return self._go("aby3_bit_inject_p2_post", _c(B0, np.int8), _c(B1, np.int8), nt, i0, n, seed20, pop20, seed12,
+                        pop12,
                         _c(from0, np.int64), _c(from1, np.int64), ("out", np.int64, n), ("out", np.int64, n))
 
     # ---- SecureNN

@@ -17,9 +17,12 @@ def pair_seed(a, b):
 class World:
     """Per-party PRG pop counters (every party owns its own PRgenerator objects, ABY3Engine.cpp:34-53)."""
 
-    def __init__(self, backend, record=True):
+    def __init__(self, backend, record=True, n_total=None, i0=0):
         self.be = backend
         self.record = record  # False: messages stay wherever the backend keeps them (device-resident timing runs)
+        # Element-range mode (one GPU's share of a vector): every vector handed to a driver holds elements
+        # [i0, i0 + n) of a vector of n_total elements; PRG offsets are those of the whole vector.
+        self.n_total, self.i0 = n_total, i0
         # pops[j][k]: words party j has popped from prgs[k] (k == j: the self stream)
         self.pops = [[0, 0, 0] for _ in range(3)]
         self.log = []
@@ -32,6 +35,10 @@ class World:
         self.pops[j][k] += count
         return p
 
+    def whole(self, n):
+        """Size of the whole vector of which the caller holds n elements."""
+        return self.n_total if self.n_total is not None else n
+
     def rec(self, tag, arr):
         if self.record:
             self.log.append((tag, np.array(arr, copy=True)))
@@ -43,8 +50,9 @@ def aby3_share(w, X, n):
     R = []
     for j in range(3):
         nx, pv = (j + 1) % 3, (j + 2) % 3
-        R.append(w.be.aby3_share_local(X if j == 0 else None, n, w.seed(j, nx), w.take(j, nx, n), w.seed(j, pv),
-                                       w.take(j, pv, n)))
+        nt = w.whole(n)
+        R.append(w.be.aby3_share_local(X if j == 0 else None, n, w.seed(j, nx), w.take(j, nx, nt) + w.i0, w.seed(j, pv),
+                                       w.take(j, pv, nt) + w.i0))
         w.rec(f"share.P{j}->P{pv}", R[j])
     return [(R[j], R[(j + 1) % 3]) for j in range(3)]
 
@@ -82,8 +90,9 @@ def aby3_vecmul(w, Xs, Ys, n):
     Z0 = []
     for j in range(3):
         nx, pv = (j + 1) % 3, (j + 2) % 3
-        Z0.append(w.be.aby3_vecmul_local(Xs[j][0], Xs[j][1], Ys[j][0], Ys[j][1], n, w.seed(j, nx), w.take(j, nx, n),
-                                         w.seed(j, pv), w.take(j, pv, n)))
+        nt = w.whole(n)
+        Z0.append(w.be.aby3_vecmul_local(Xs[j][0], Xs[j][1], Ys[j][0], Ys[j][1], n, w.seed(j, nx),
+                                         w.take(j, nx, nt) + w.i0, w.seed(j, pv), w.take(j, pv, nt) + w.i0))
     return [(Z0[j], Z0[(j + 1) % 3]) for j in range(3)]
 
 
@@ -121,17 +130,19 @@ def aby3_bit_inject(w, As, Bs):
     """bit_inject (ABY3Engine.cpp:510-1038)."""
     be = w.be
     n = As[0][0].size
-    p01_0, p20_0 = w.take(0, 1, 6 * n), w.take(0, 2, 3 * n)
-    p01_1, p12_1 = w.take(1, 0, 6 * n), w.take(1, 2, 3 * n)
-    p20_2, p12_2 = w.take(2, 0, 3 * n), w.take(2, 1, 3 * n)
-    m01, m02 = be.aby3_bit_inject_p0_pre(As[0][0], Bs[0][0], Bs[0][1], KEY01, p01_0, KEY20, p20_0)
-    m10, m12 = be.aby3_bit_inject_p1_pre(As[1][0], As[1][1], Bs[1][0], Bs[1][1], KEY01, p01_1, KEY12, p12_1)
-    m20, m21 = be.aby3_bit_inject_p2_pre(Bs[2][0], Bs[2][1], KEY20, p20_2, KEY12, p12_2)
+    nt = w.whole(n)
+    rng = (nt, w.i0)
+    p01_0, p20_0 = w.take(0, 1, 6 * nt), w.take(0, 2, 3 * nt)
+    p01_1, p12_1 = w.take(1, 0, 6 * nt), w.take(1, 2, 3 * nt)
+    p20_2, p12_2 = w.take(2, 0, 3 * nt), w.take(2, 1, 3 * nt)
+    m01, m02 = be.aby3_bit_inject_p0_pre(As[0][0], Bs[0][0], Bs[0][1], KEY01, p01_0, KEY20, p20_0, rng=rng)
+    m10, m12 = be.aby3_bit_inject_p1_pre(As[1][0], As[1][1], Bs[1][0], Bs[1][1], KEY01, p01_1, KEY12, p12_1, rng=rng)
+    m20, m21 = be.aby3_bit_inject_p2_pre(Bs[2][0], Bs[2][1], KEY20, p20_2, KEY12, p12_2, rng=rng)
     for tag, m in (("01", m01), ("02", m02), ("10", m10), ("12", m12), ("20", m20), ("21", m21)):
         w.rec("bit_inject.P%s->P%s" % (tag[0], tag[1]), m)
-    C = [be.aby3_bit_inject_p0_post(Bs[0][0], KEY01, p01_0, KEY20, p20_0, m10, m20),
-         be.aby3_bit_inject_p1_post(Bs[1][1], KEY01, p01_1, KEY12, p12_1, m01, m21),
-         be.aby3_bit_inject_p2_post(Bs[2][0], Bs[2][1], KEY20, p20_2, KEY12, p12_2, m02, m12)]
+    C = [be.aby3_bit_inject_p0_post(Bs[0][0], KEY01, p01_0, KEY20, p20_0, m10, m20, rng=rng),
+         be.aby3_bit_inject_p1_post(Bs[1][1], KEY01, p01_1, KEY12, p12_1, m01, m21, rng=rng),
+         be.aby3_bit_inject_p2_post(Bs[2][0], Bs[2][1], KEY20, p20_2, KEY12, p12_2, m02, m12, rng=rng)]
     return C
 
 
@@ -139,16 +150,17 @@ def aby3_trunc(w, Xs, number):
     """trunc (ABY3Engine.cpp:469-508): P1 and P2 pop the stream they share."""
     n = Xs[0][0].size
     Y0 = [w.be.aby3_trunc_local(0, Xs[0][0], Xs[0][1], number, KEY12, 0),
-          w.be.aby3_trunc_local(1, Xs[1][0], Xs[1][1], number, KEY12, w.take(1, 2, n)),
-          w.be.aby3_trunc_local(2, Xs[2][0], Xs[2][1], number, KEY12, w.take(2, 1, n))]
+          w.be.aby3_trunc_local(1, Xs[1][0], Xs[1][1], number, KEY12, w.take(1, 2, w.whole(n)) + w.i0),
+          w.be.aby3_trunc_local(2, Xs[2][0], Xs[2][1], number, KEY12, w.take(2, 1, w.whole(n)) + w.i0)]
     return [(Y0[j], Y0[(j + 1) % 3]) for j in range(3)]
 
 
 # ------------------------------------------------------------------ SecureNN
 def snn_share(w, X, n):
     """SecurennEngine::share (SecurennEngine.cpp:318-334).  Returns [X_0, X_1, zeros]."""
-    return [w.be.snn_share_local(0, None, n, KEY01, w.take(0, 1, n)),
-            w.be.snn_share_local(1, X, n, KEY01, w.take(1, 0, n)),
+    nt = w.whole(n)
+    return [w.be.snn_share_local(0, None, n, KEY01, w.take(0, 1, nt) + w.i0),
+            w.be.snn_share_local(1, X, n, KEY01, w.take(1, 0, nt) + w.i0),
             w.be.snn_share_local(2, None, n, KEY01, 0)]
 
 
@@ -175,7 +187,7 @@ def snn_vecmul(w, Xs, Ys):
     """vector_mul (SecurennEngine.cpp:171-316)."""
     be = w.be
     n = Xs[0].size
-    A0, B0, C0, A1, B1, C1 = be.snn_beaver_dealer_vecmul(KEYS, n, 0, n)
+    A0, B0, C0, A1, B1, C1 = be.snn_beaver_dealer_vecmul(KEYS, w.whole(n), w.i0, n)
     for tag, m in (("A0", A0), ("B0", B0), ("C0", C0), ("A1", A1), ("B1", B1), ("C1", C1)):
         w.rec("snn_vecmul.P2." + tag, m)
     E0, F0 = be.snn_beaver_party_open_vecmul(Xs[0], Ys[0], A0, B0)
@@ -191,8 +203,9 @@ def snn_private_compare(w, xbits, beta, r):
     """privateCompare (SecurennEngine.cpp:507-680).  xbits = [share of P0, share of P1]; returns beta' at P2."""
     be = w.be
     n = beta.size
-    d0 = be.snn_pc_party(0, xbits[0], beta, r, n, 0, KEY01)
-    d1 = be.snn_pc_party(1, xbits[1], beta, r, n, 0, KEY01)
+    nt, i0 = w.whole(n), w.i0
+    d0 = be.snn_pc_party(0, xbits[0], beta, r, nt, i0, KEY01)
+    d1 = be.snn_pc_party(1, xbits[1], beta, r, nt, i0, KEY01)
     w.rec("pc.P0->P2", d0)
     w.rec("pc.P1->P2", d1)
     b = be.snn_pc_helper(d0, d1)
@@ -204,20 +217,21 @@ def snn_share_convert(w, As):
     """shareConvert (SecurennEngine.cpp:685-893).  As = [a_0, a_1]; returns [y_0, y_1] over Z_{2^64-1}."""
     be = w.be
     n = As[0].size
-    x0 = be.snn_sc_party_open(0, As[0], n, 0, KEY01)
-    x1 = be.snn_sc_party_open(1, As[1], n, 0, KEY01)
+    nt, i0 = w.whole(n), w.i0
+    x0 = be.snn_sc_party_open(0, As[0], nt, i0, KEY01)
+    x1 = be.snn_sc_party_open(1, As[1], nt, i0, KEY01)
     w.rec("sc.x0", x0)
     w.rec("sc.x1", x1)
-    xb0, dl0, xb1, dl1 = be.snn_sc_helper_split(x0, x1, n, 0, KEYS)
+    xb0, dl0, xb1, dl1 = be.snn_sc_helper_split(x0, x1, nt, i0, KEYS)
     for tag, m in (("xb0", xb0), ("dl0", dl0), ("xb1", xb1), ("dl1", dl1)):
         w.rec("sc.P2." + tag, m)
-    eta2, rm1 = be.snn_sc_party_pc_inputs(n, 0, n, KEY01)
+    eta2, rm1 = be.snn_sc_party_pc_inputs(nt, i0, n, KEY01)
     eta1 = snn_private_compare(w, [xb0, xb1], eta2, rm1)
-    e0, e1 = be.snn_sc_helper_eta(eta1, n, 0, KEYS)
+    e0, e1 = be.snn_sc_helper_eta(eta1, nt, i0, KEYS)
     w.rec("sc.P2.eta0", e0)
     w.rec("sc.P2.eta1", e1)
-    y0 = be.snn_sc_party_finish(0, As[0], dl0, e0, n, 0, KEY01)
-    y1 = be.snn_sc_party_finish(1, As[1], dl1, e1, n, 0, KEY01)
+    y0 = be.snn_sc_party_finish(0, As[0], dl0, e0, nt, i0, KEY01)
+    y1 = be.snn_sc_party_finish(1, As[1], dl1, e1, nt, i0, KEY01)
     return [y0, y1]
 
 
@@ -225,19 +239,20 @@ def snn_msb_L1(w, Ys):
     """msb_L_1 (SecurennEngine.cpp:898-1084).  Ys over Z_{2^64-1}; returns shares of the msb over Z_2^64."""
     be = w.be
     n = Ys[0].size
-    x0, l0, xb0, x1, l1, xb1 = be.snn_msbl1_helper_deal(n, 0, n, KEYS)
+    nt, i0 = w.whole(n), w.i0
+    x0, l0, xb0, x1, l1, xb1 = be.snn_msbl1_helper_deal(nt, i0, n, KEYS)
     for tag, m in (("x0", x0), ("l0", l0), ("xb0", xb0), ("x1", x1), ("l1", l1), ("xb1", xb1)):
         w.rec("msbl1.P2." + tag, m)
     r0 = be.snn_msbl1_party_open(Ys[0], x0)
     r1 = be.snn_msbl1_party_open(Ys[1], x1)
     w.rec("msbl1.r0", r0)
     w.rec("msbl1.r1", r1)
-    beta0, R = be.snn_msbl1_party_pc_inputs(r0, r1, 0, KEY01)
+    beta0, R = be.snn_msbl1_party_pc_inputs(r0, r1, i0, KEY01)
     if w.record:  # party 1 derives the same pair
-        beta0b, Rb = be.snn_msbl1_party_pc_inputs(r1, r0, 0, KEY01)
+        beta0b, Rb = be.snn_msbl1_party_pc_inputs(r1, r0, i0, KEY01)
         assert np.array_equal(R, Rb) and np.array_equal(beta0, beta0b)
     beta1 = snn_private_compare(w, [xb0, xb1], beta0, R)
-    b0, b1 = be.snn_msbl1_helper_beta(beta1, n, 0, KEYS)
+    b0, b1 = be.snn_msbl1_helper_beta(beta1, nt, i0, KEYS)
     w.rec("msbl1.P2.b0", b0)
     w.rec("msbl1.P2.b1", b1)
     g0, d0 = be.snn_msbl1_party_mid(0, b0, l0, beta0, R)

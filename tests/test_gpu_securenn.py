@@ -237,3 +237,19 @@ def test_snn_small_segments_parity(gpu, orc):
         assert np.array_equal(gpu.snn_sc_party_open(party, a, 1000, 100, KEY01), orc.snn_sc_party_open(party, a, 1000, 100, KEY01))
         assert np.array_equal(gpu.snn_sc_party_finish(party, a, b, orc.snn_add_L1(a, a), 1000, 100, KEY01),
                               orc.snn_sc_party_finish(party, a, b, orc.snn_add_L1(a, a), 1000, 100, KEY01))
+
+
+@pytest.mark.timeout(400)
+def test_private_compare_range_beyond_32_bit_stream_offsets(gpu, orc):
+    """A range at the end of a 2^24 + 2^23 element vector: its u words sit past stream word 2^32 of the s01
+    generator (256 stream words per element), which is where an 8-GPU run of 2^24 elements per GPU works."""
+    nt = (1 << 24) + (1 << 23)
+    n, i0 = 1003, nt - 1003
+    x, r, beta, s0, s1 = pc_inputs(n)
+    beta[:] = 1  # with r = -1 on every fifth element: the branch that reads u (SecurennEngine.cpp:577-585)
+    want = orc.snn_pc_party(0, s0, beta, r, nt, i0, KEY01)
+    got = gpu.snn_pc_party(0, s0, beta, r, nt, i0, KEY01)
+    assert np.array_equal(got, want)
+    ints_o, bools_o = orc.prg_fill_buff(KEY01, 128 * nt - 700, 700)
+    ints_g, bools_g = gpu.prg_fill_buff(KEY01, 128 * nt - 700, 700)
+    assert np.array_equal(ints_g, ints_o) and np.array_equal(bools_g, bools_o)

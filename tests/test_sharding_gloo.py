@@ -80,3 +80,17 @@ def test_split_range_covers_everything():
             assert got[0][0] == 0 and sum(c for _, c in got) == total
             for (f0, c0), (f1, _) in zip(got, got[1:]):
                 assert f0 + c0 == f1
+
+
+def test_snn_msb_in_element_ranges(orc):
+    """The SecureNN msb protocol run range by range (n_total, i0, n) gives the whole vector's messages and shares
+    (the CPU restatement takes the same range arguments as the device segments)."""
+    import protocols as pr
+    from oracle_lib import prg_pops
+    from range_helpers import run_in_ranges, same_logs, snn_msb
+    a = prg_pops(22, 0, 1200) >> 1
+    wo = pr.World(orc)
+    want = snn_msb(wo, a)
+    got, log = run_in_ranges(orc, snn_msb, a, ((0, 500), (500, 1), (501, 699)))
+    same_logs(log, wo.log)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
