@@ -382,7 +382,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     gemm_ms, gemm_cnt = prof_read(ctx, "limb_gemm")
-    breakdown = {k: round(prof_read(ctx, k)[0] / args.steps, 3) for k in ("limb_gemm", "split_limbs", "combine", "prg_fill")}
+    breakdown = {k: round(prof_read(ctx, k)[0] / args.steps, 3) for k in ("limb_gemm", "split_limbs", "prg_fill")}
     ctx.call("profile", 0)
     if not args.no_verify:
         job.verify()

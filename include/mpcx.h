@@ -53,7 +53,7 @@ int mpcx_d2h(mpcx_ctx *ctx, void *dst, const void *src, uint64_t bytes);
 int mpcx_d2d(mpcx_ctx *ctx, void *dst, const void *src, uint64_t bytes);
 /* per-kernel device timing with HIP events recorded on the context's stream: mpcx_profile(ctx,1) starts
  * (and clears) the collection, mpcx_profile_read sums the elapsed time of every launch of one kernel
- * family since then: "limb_gemm", "split_limbs", "combine", "prg_fill", "pc_party", "pc_helper",
+ * family since then: "limb_gemm", "split_limbs", "prg_fill", "pc_party", "pc_helper",
  * "msb_round" */
 int mpcx_profile(mpcx_ctx *ctx, int enable);
 int mpcx_profile_read(mpcx_ctx *ctx, const char *kernel, double *total_ms, uint64_t *launches);

@@ -214,19 +214,15 @@ int mpcx_aby3_share_bools_local(mpcx_ctx *ctx, const int8_t *X, uint64_t n, uint
 }
 
 // Z0 = X0*(Y0+Y1) + X1*Y0 = [X0 | X1] * [Y0+Y1 ; Y0]  (ABY3Engine.cpp:189) as ONE K-concatenated ring
-// product, with the mask pop(next) - pop(prev) (:190-197) fused into the recombination pass.
+// product, with the mask pop(next) - pop(prev) (:190-197) added in the product's epilogue.
 static int aby3_matmul_impl(mpcx_ctx *ctx, const i64 *X0, const i64 *X1, const i64 *Y0, const i64 *Y1, u64 rows, u64 l,
                             u64 c, int layout, u64 first_word, u64 seed_next, u64 pop_next, u64 seed_prev, u64 pop_prev,
                             i64 *Z0) {
-    const u64 nz = rows * c;
-    const u64 gemm_bytes = ring_gemm_ws_bytes(2, rows, l, c);
-    void *ws;
-    MPCX_TRY(mpcx_ws(ctx, gemm_bytes + 8 * nz, &ws)); // the gemm driver takes the front, the mask words the tail
-    i64 *mask = (i64 *)((u8 *)ws + gemm_bytes);
-    MPCX_TRY(prg_fill_diff(ctx, seed_next, PRG_POP_T0 + pop_next + first_word, seed_prev, PRG_POP_T0 + pop_prev + first_word, nz,
-                           nullptr, mask));
+    // the mask words go straight into Z0 and the product is accumulated onto them
+    MPCX_TRY(prg_fill_diff(ctx, seed_next, PRG_POP_T0 + pop_next + first_word, seed_prev, PRG_POP_T0 + pop_prev + first_word,
+                           rows * c, nullptr, Z0));
     GemmPart parts[2] = {{X0, Y0, Y1}, {X1, Y0, nullptr}};
-    return ring_gemm_parts(ctx, parts, 2, rows, l, c, layout, layout, mask, nullptr, Z0, 0, 0);
+    return ring_gemm_parts(ctx, parts, 2, rows, l, c, layout, layout, nullptr, nullptr, Z0, 0, 1);
 }
 
 int mpcx_aby3_matmul_local_rows(mpcx_ctx *ctx, const int64_t *X0, const int64_t *X1, const int64_t *Y0,

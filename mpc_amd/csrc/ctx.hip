@@ -167,7 +167,7 @@ int mpcx_d2d(mpcx_ctx *ctx, void *dst, const void *src, uint64_t bytes) {
     MPCX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
     return 0;
 }
-static const char *kProfNames[PROF_SLOTS] = {"limb_gemm", "split_limbs", "combine", "prg_fill", "pc_party", "pc_helper", "msb_round"};
+static const char *kProfNames[PROF_SLOTS] = {"limb_gemm", "split_limbs", "prg_fill", "pc_party", "pc_helper", "msb_round"};
 
 int mpcx_profile(mpcx_ctx *ctx, int enable) {
     MPCX_HIP(hipStreamSynchronize(ctx->stream));

@@ -28,7 +28,7 @@ constexpr u64 PRG_CK = 256;        // stream words per checkpoint
 constexpr u64 PRG_POP_T0 = 320000; // stream word of the first pop (2 * BUFF_NUM, utils/PRgenerator.hpp:6)
 
 // optional per-kernel timing with HIP events on the context's stream (mpcx_profile / mpcx_profile_read)
-enum ProfSlotId { PROF_GEMM = 0, PROF_SPLIT, PROF_COMBINE, PROF_PRG, PROF_PC_PARTY, PROF_PC_HELPER, PROF_MSB, PROF_SLOTS };
+enum ProfSlotId { PROF_GEMM = 0, PROF_SPLIT, PROF_PRG, PROF_PC_PARTY, PROF_PC_HELPER, PROF_MSB, PROF_SLOTS };
 
 struct mpcx_ctx {
     bool prof = false;

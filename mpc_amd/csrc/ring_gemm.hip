@@ -7,8 +7,8 @@
 // accumulation chunk (larger K is split into chunks that are recombined in 64 bits).
 //
 // Pipeline:  split_limbs (u64 matrix -> 8 int8 limb planes, optionally two sources concatenated
-// along K)  ->  limb_gemm (v_mfma_i32_32x32x32_i8; one int32 plane per s)  ->  combine (shift-add the
-// planes in 64 bits, fuse the PRG mask / accumulation).
+// along K)  ->  limb_gemm (v_mfma_i32_32x32x32_i8; the eight P_s of an output element stay in the registers
+// of one lane and are shift-added in 64 bits in the epilogue, which also adds the mask / accumulates).
 //
 // Limb planes are stored K-blocked: plane[i][kb][row][32 bytes], kb = k / 32, so that the operand
 // tile of one K step (a run of rows x 32 bytes) is one contiguous, fully used piece of memory.
@@ -72,13 +72,14 @@ __global__ __launch_bounds__(256) void split_limbs_kernel(const u64 *__restrict_
 }
 
 // ---------------------------------------------------------------- gemm
-// Cpl[s][m][n] = sum_{i+j=s} sum_k Apl[i][m][k] * Bpl[j][n][k]  (int32) for one 128 x 64 block tile.
+// Z[m][n] (+)= sum_s 256^s * sum_{i+j=s} sum_k Apl[i][m][k] * Bpl[j][n][k]  (+ add - sub) for one 128 x 64 block tile;
+// add / sub are row-major M x N word arrays, Z is addressed as m * ldz_row + n * ldz_col.
 //
 // Eight waves as 4(M) x 2(N); every wave owns ONE 32x32 output tile and keeps all eight s-accumulators
 // (8 x 16 registers).  Per K step the block stages the 8 limb tiles of A (8 x 128 x 32 B) and of B
 // (8 x 64 x 32 B) once -- 48 KiB -- and every wave issues the 36 MFMAs i+j <= 7 on them: each staged
 // byte feeds 192 multiply-adds (a plain one-accumulator 256x256 tiling feeds 128), and the accumulators
-// are written out once, after the whole K loop.
+// never leave the registers: after the K loop each lane folds its eight int32 sums per element into one word.
 //
 // Staging is LDS-DMA (global_load_lds, 16 B per lane) into three 48 KiB buffers (steps t+1 and t+2 land while
 // step t is multiplied).  A DMA wave-instruction writes 1 KiB linearly = 32 rows x 32 B, so the bank swizzle
@@ -92,7 +93,9 @@ __global__ __launch_bounds__(256) void split_limbs_kernel(const u64 *__restrict_
 // ABL (development ablation, 0 in production): 1 = no MFMA / fragment reads, 2 = no operand staging.
 template <int ABL>
 __global__ __launch_bounds__(512) void limb_gemm_kernel(const i8 *__restrict__ Apl, const i8 *__restrict__ Bpl,
-                                                        i32 *__restrict__ Cpl, u32 Mp, u32 Np, u32 nkb, u32 tiles_m,
+                                                        u64 *__restrict__ Z, u32 M, u32 N, u64 ldz_row, u64 ldz_col,
+                                                        const u64 *__restrict__ add, const u64 *__restrict__ sub,
+                                                        int accumulate, u32 Mp, u32 Np, u32 nkb, u32 tiles_m,
                                                         u32 tiles_n, u32 GM) {
     __shared__ __attribute__((aligned(1024))) i8 lds[3 * STAGE_BYTES]; // 144 KiB: three staging buffers
     const u32 tid = threadIdx.x, lane = tid & 63;
@@ -252,14 +255,25 @@ __global__ __launch_bounds__(512) void limb_gemm_kernel(const i8 *__restrict__ A
 #undef MPCX_PIN
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 
-    const u64 strideC = (u64)Mp * Np;
+    // ---- epilogue: one 64-bit word per element.  For a fixed register index the 64 lanes cover two rows x 32
+    // consecutive columns, i.e. two 256-byte runs of a row-major Z.
     const u32 col = tn * RN + wn * 32 + lr;
     const u32 row0 = tm * RM + wm * 32 + 4 * lh;
+    if (col < N) {
 #pragma unroll
-    for (u32 s = 0; s < 8; s++) {
-        i32 *Cs = Cpl + s * strideC + col;
+        for (u32 r = 0; r < 16; r++) {
+            const u32 row = row0 + (r & 3) + 8 * (r >> 2);
+            if (row >= M) continue;
+            u64 z = 0;
 #pragma unroll
-        for (u32 r = 0; r < 16; r++) Cs[(u64)(row0 + (r & 3) + 8 * (r >> 2)) * Np] = acc[s][r];
+            for (u32 s = 0; s < 8; s++) z += (u64)(i64)acc[s][r] << (8 * s);
+            const u64 idx = (u64)row * N + col;
+            if (add) z += add[idx];
+            if (sub) z -= sub[idx];
+            const u64 zi = row * ldz_row + col * ldz_col;
+            if (accumulate) z += Z[zi];
+            Z[zi] = z;
+        }
     }
 }
 
@@ -304,27 +318,7 @@ __global__ __launch_bounds__(512) void limb_gemm_shape_probe(i32 *__restrict__ C
     *(v4i *)out = sum;
 }
 
-// ---------------------------------------------------------------- combine
-// Z[m][n] (+)= sum_s (int64)Cpl[s][m][n] << 8s  (+ add[idx] - sub[idx]), idx = m*N + n (row-major)
-__global__ __launch_bounds__(256) void combine_kernel(const i32 *__restrict__ Cpl, u64 Mp, u64 Np, u64 M, u64 N,
-                                                      const u64 *__restrict__ add, const u64 *__restrict__ sub,
-                                                      u64 *__restrict__ Z, u64 ldz_row, u64 ldz_col, int accumulate) {
-    const u64 total = M * N;
-    const u64 strideC = Mp * Np;
-    for (u64 idx = (u64)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (u64)gridDim.x * 256) {
-        const u64 m = idx / N, n = idx - m * N;
-        const i32 *p = Cpl + m * Np + n;
-        u64 z = 0;
-#pragma unroll
-        for (u32 s = 0; s < 8; s++) z += (u64)(i64)p[s * strideC] << (8 * s);
-        if (add) z += add[idx];
-        if (sub) z -= sub[idx];
-        const u64 zi = m * ldz_row + n * ldz_col;
-        if (accumulate) z += Z[zi];
-        Z[zi] = z;
-    }
-}
-
+// ---------------------------------------------------------------- relayout
 __global__ __launch_bounds__(256) void relayout_kernel(const u64 *__restrict__ src, u64 *__restrict__ dst, u64 rows,
                                                        u64 cols, int lay_src, int lay_dst) {
     __shared__ u64 tile[32][33];
@@ -356,8 +350,8 @@ static u64 part_chunk_len(int nparts, u64 l) {
 
 u64 ring_gemm_ws_bytes(int nparts, u64 r, u64 l, u64 c) {
     const u64 Mp = round_up(r, RM), Np = round_up(c, RM), Kp = (u64)nparts * part_chunk_len(nparts, l);
-    const u64 bytesA = 8 * Mp * Kp, bytesB = 8 * Np * Kp, bytesC = 8 * Mp * Np * 4;
-    return ((bytesA + 255) & ~255ull) + ((bytesB + 255) & ~255ull) + ((bytesC + 255) & ~255ull);
+    const u64 bytesA = 8 * Mp * Kp, bytesB = 8 * Np * Kp;
+    return ((bytesA + 255) & ~255ull) + ((bytesB + 255) & ~255ull);
 }
 
 int ring_gemm_parts(mpcx_ctx *ctx, const GemmPart *parts, int nparts, u64 r, u64 l, u64 c, int layA, int layB,
@@ -376,7 +370,7 @@ int ring_gemm_parts(mpcx_ctx *ctx, const GemmPart *parts, int nparts, u64 r, u64
     MPCX_TRY(mpcx_ws(ctx, ring_gemm_ws_bytes(nparts, r, l, c), &ws));
     i8 *Apl = (i8 *)ws;
     i8 *Bpl = Apl + ((bytesA + 255) & ~255ull);
-    i32 *Cpl = (i32 *)(Bpl + ((bytesB + 255) & ~255ull));
+    (void)bytesB;
     const u32 tiles_m = (u32)(Mp / RM), tiles_n = (u32)(Np / RN);
     const u32 nkb = (u32)(Kp / RK);
     const u64 soA = layA ? 1 : l, skA = layA ? r : 1; // A(o=row, k)
@@ -399,25 +393,21 @@ int ring_gemm_parts(mpcx_ctx *ctx, const GemmPart *parts, int nparts, u64 r, u64
         {
             ProfScope ps(ctx, PROF_GEMM);
             const dim3 grid(tiles_m * tiles_n), block(512);
-            if (abl == 3)
-                hipLaunchKernelGGL(limb_gemm_shape_probe, grid, block, 0, ctx->stream, Cpl, (u32)Mp, (u32)Np, nkb);
+            const bool last = kb + lc >= l;
+            const u64 *ad = last ? (const u64 *)add : nullptr, *sb = last ? (const u64 *)sub : nullptr;
+            const u64 ldr = layZ ? (u64)1 : c, ldc = layZ ? r : (u64)1;
+            const int acc = (accumulate || !first) ? 1 : 0;
+#define MPCX_GEMM_ARGS Apl, Bpl, (u64 *)Z, (u32)r, (u32)c, ldr, ldc, ad, sb, acc, (u32)Mp, (u32)Np, nkb, tiles_m, tiles_n, gm
+            if (abl == 3) // timing probe only: scribbles over Z
+                hipLaunchKernelGGL(limb_gemm_shape_probe, grid, block, 0, ctx->stream, (i32 *)Z, (u32)r, (u32)c, nkb);
             else if (abl == 1)
-                hipLaunchKernelGGL(limb_gemm_kernel<1>, grid, block, 0, ctx->stream, Apl, Bpl, Cpl, (u32)Mp, (u32)Np, nkb,
-                                   tiles_m, tiles_n, gm);
+                hipLaunchKernelGGL(limb_gemm_kernel<1>, grid, block, 0, ctx->stream, MPCX_GEMM_ARGS);
             else if (abl == 2)
-                hipLaunchKernelGGL(limb_gemm_kernel<2>, grid, block, 0, ctx->stream, Apl, Bpl, Cpl, (u32)Mp, (u32)Np, nkb,
-                                   tiles_m, tiles_n, gm);
+                hipLaunchKernelGGL(limb_gemm_kernel<2>, grid, block, 0, ctx->stream, MPCX_GEMM_ARGS);
             else
-                hipLaunchKernelGGL(limb_gemm_kernel<0>, grid, block, 0, ctx->stream, Apl, Bpl, Cpl, (u32)Mp, (u32)Np, nkb,
-                                   tiles_m, tiles_n, gm);
+                hipLaunchKernelGGL(limb_gemm_kernel<0>, grid, block, 0, ctx->stream, MPCX_GEMM_ARGS);
+#undef MPCX_GEMM_ARGS
         }
-        const u64 total = r * c;
-        const u32 grid = (u32)(ceil_div(total, 256) < MPCX_MAX_GRID ? ceil_div(total, 256) : MPCX_MAX_GRID);
-        const bool last = kb + lc >= l;
-        ProfScope pc(ctx, PROF_COMBINE);
-        hipLaunchKernelGGL(combine_kernel, dim3(grid), dim3(256), 0, ctx->stream, Cpl, Mp, Np, r, c,
-                           last ? (const u64 *)add : nullptr, last ? (const u64 *)sub : nullptr, (u64 *)Z,
-                           layZ ? (u64)1 : c, layZ ? r : (u64)1, (accumulate || !first) ? 1 : 0);
         first = 0;
     }
     MPCX_LAUNCH_CHECK();
