@@ -19,12 +19,15 @@ typedef uint16_t u16;
 typedef int8_t i8;
 typedef uint8_t u8;
 
-// One checkpoint of a prvhash stream: the generator state before stream word t = 256 * index,
+// One checkpoint of a prvhash stream: the generator state before stream word t = PRG_CK * index,
 // where stream word t is raw output #(5 + t) of PRgenerator(seed, lcg) (utils/PRgenerator.cpp:21-33).
 struct PrgCk {
-    u64 seed, lcg, hash, pad;
+    u64 seed, lcg, hash;
 };
-constexpr u64 PRG_CK = 256;        // stream words per checkpoint
+// Stream words per checkpoint = words one lane regenerates.  64 keeps a 2^24-word fill at four waves per SIMD
+// (256 left it at one, and the dependent multiply chain then ran at 40 % of its issue rate); the table costs
+// 0.375 bytes per stream word.
+constexpr u64 PRG_CK = 64;
 constexpr u64 PRG_POP_T0 = 320000; // stream word of the first pop (2 * BUFF_NUM, utils/PRgenerator.hpp:6)
 
 // optional per-kernel timing with HIP events on the context's stream (mpcx_profile / mpcx_profile_read)

@@ -2,8 +2,8 @@
 //
 // prvhash-core64 has no jump-ahead (the state advances through a data-dependent multiply), so the
 // stream is made parallel with a checkpoint table: the host walks the stream once and keeps the
-// 24-byte state every PRG_CK = 256 outputs; one GPU lane then replays one 256-word segment.  A
-// 256-thread workgroup therefore owns 256 segments (512 KiB of output); every 16 steps the lanes
+// 24-byte state every PRG_CK outputs; one GPU lane then replays one PRG_CK-word segment.  A
+// 256-thread workgroup therefore owns 256 consecutive segments; every 16 steps the lanes
 // park their words in LDS and the workgroup writes them out as whole 128-byte lines.
 #include <map>
 #include <mutex>
@@ -31,7 +31,7 @@ __host__ __device__ inline u64 prv_step(u64 &seed, u64 &lcg, u64 &hash) {
 }
 
 struct Table {
-    std::vector<PrgCk> host; // host[e] = state before stream word 256*e
+    std::vector<PrgCk> host; // host[e] = state before stream word PRG_CK*e
     PrgCk *dev = nullptr;
     u64 dev_cap = 0, dev_count = 0;
     std::vector<PrgCk *> retired; // older device copies a kernel in flight may still read
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void prg_fill_kernel(const PrgCk *__restrict__
         lcg = c.lcg;
         hash = c.hash;
     }
-    for (u32 it = 0; it < 16; it++) {
+    for (u32 it = 0; it < PRG_CK / 16; it++) {
 #pragma unroll
         for (u32 k = 0; k < 16; k++) tile[tid * 17 + k] = prv_step(seed, lcg, hash);
         __syncthreads();
@@ -101,14 +101,14 @@ __global__ __launch_bounds__(256) void prg_fill_kernel(const PrgCk *__restrict__
 
 // out[i] = (X ? X[i] : 0) + A[tA_first + i] - B[tB_first + i] for two streams A, B (the mask pop(next) - pop(prev)
 // that the ABY3 share and product segments add, ABY3Engine.cpp:70-74, :190-197) without materialising either stream.
-// One lane owns 256 consecutive outputs; for each stream it starts from the checkpoint below its first word and
-// discards the words in between (none when the stream offsets are multiples of 256, as the pop stream's origin is).
+// One lane owns PRG_CK consecutive outputs; for each stream it starts from the checkpoint below its first word and
+// discards the words in between (none when the stream offsets are multiples of PRG_CK, as the pop stream's origin is).
 __global__ __launch_bounds__(256) void prg_diff_kernel(const PrgCk *__restrict__ ckA, const PrgCk *__restrict__ ckB,
                                                        u64 tA_first, u64 tB_first, u64 count,
                                                        const u64 *__restrict__ X, u64 *__restrict__ out) {
     __shared__ u64 tile[256 * 17];
     const u32 tid = threadIdx.x;
-    const u64 blk_r0 = (u64)blockIdx.x * 256; // first 256-output run of this workgroup
+    const u64 blk_r0 = (u64)blockIdx.x * 256; // first run of PRG_CK outputs of this workgroup
     const u64 run = blk_r0 + tid;
     const bool active = run * PRG_CK < count;
     u64 sa = 0, la = 0, ha = 0, sb = 0, lb = 0, hb = 0;
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void prg_diff_kernel(const PrgCk *__restrict__
     }
     for (u32 i = 0; i < skipA; i++) prv_step(sa, la, ha);
     for (u32 i = 0; i < skipB; i++) prv_step(sb, lb, hb);
-    for (u32 it = 0; it < 16; it++) {
+    for (u32 it = 0; it < PRG_CK / 16; it++) {
 #pragma unroll
         for (u32 k = 0; k < 16; k++) {
             const u64 wa = prv_step(sa, la, ha);
@@ -150,9 +150,9 @@ int mpcx_prg_table(mpcx_ctx *ctx, u64 seed, u64 lcg, u64 t_end, const PrgCk **de
     if (T.host.empty()) {
         u64 s = seed, l = lcg, h = 0;
         for (int i = 0; i < 5; i++) prv_step(s, l, h); // utils/PRgenerator.cpp:23-26
-        T.host.push_back(PrgCk{s, l, h, 0});
+        T.host.push_back(PrgCk{s, l, h});
     }
-    const u64 need = t_end / PRG_CK + 1; // checkpoints 0 .. floor(t_end/256)
+    const u64 need = t_end / PRG_CK + 1; // checkpoints 0 .. floor(t_end/PRG_CK)
     if (T.host.size() < need) {
         T.host.reserve(need);
         PrgCk c = T.host.back();
