@@ -126,9 +126,9 @@ int mpcx_aby3_reveal3_bits(mpcx_ctx *ctx, const int64_t *a, const int64_t *b, co
 int mpcx_aby3_add_prepare_step1(mpcx_ctx *ctx, const int64_t *X0, const int64_t *X1, uint64_t n, int64_t *C0);
 int mpcx_aby3_add_prepare_step2(mpcx_ctx *ctx, const int64_t *X0, const int64_t *X1, const int64_t *C0,
                                 const int64_t *C1, uint64_t n, int64_t *P0, int64_t *P1, int64_t *G0);
-/* msb (:361-467), six rounds temp = 32,16,8,4,2,1.  The carry tree is kept as packed words (bit b of
- * element k = the reference's byte k*2*temp+b) whose width halves every round; `state` is an opaque
- * scratch of 6*n 64-bit words owned by the caller for the duration of one msb.
+/* msb (:361-467), six rounds temp = 32,16,8,4,2,1.  The carry tree is kept as dense bit strings (bit
+ * 2*temp*k + b of a level's string = the reference's byte k*2*temp+b) that halve every round; `state` is an
+ * opaque scratch of 6*n 64-bit words owned by the caller for the duration of one msb.
  *  begin:      copies the inputs into state and applies :385-387 (G[63]=0, P[63]=1)
  *  round_pre:  builds this round's vecbool_mul product share (:397-414, :253-256), writes it to msg_out
  *              (2*temp bytes per element, the byte order of result[0]) and advances share 0 of the state

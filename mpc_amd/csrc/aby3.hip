@@ -18,138 +18,111 @@ template <class F> int ew_launch(mpcx_ctx *ctx, u64 n, F f) {
     return 0;
 }
 
-// ---- msb() carry tree (ABY3Engine.cpp:361-467) on packed words ----------------------------------------------
-// The reference keeps one byte per bit and halves the vectors every round.  Here the 2*TEMP bits an element
-// still has before the round with TEMP pairs are kept dense in the low bits of one word per share array
-// (G0, G1, P0, P1), and every round writes words of half the width: u64 -> u32 -> u16 -> u8 (4, 2, 1 bits).
-// `state` is 48*n bytes; the arrays of each level live at fixed offsets so that a round never writes what
-// another lane of the same launch still reads:
-//   level (pairs) : 32      16       8       4       2       1       0 (result)
-//   byte offset   : 0       32n      0       8n      12n     16n     20n
-//   word bytes    : 8       4        2       1       1       1       1
-template <u32 TEMP> struct MsbLevel {
-    static constexpr u32 BYTES = TEMP == 32 ? 8 : TEMP == 16 ? 4 : TEMP == 8 ? 2 : 1;
-    static constexpr u32 BASE = TEMP == 32 ? 0 : TEMP == 16 ? 32 : TEMP == 8 ? 0 : TEMP == 4 ? 8 : TEMP == 2 ? 12 : TEMP == 1 ? 16 : 20;
-    static constexpr u32 G = TEMP >= 4 ? TEMP / 4 : 1; // lanes per element in this level's round
-    static constexpr u32 NP = TEMP >= 4 ? 4 : TEMP;    // pairs per lane = 2*NP wire bytes
-    static constexpr u64 EVEN = TEMP == 32 ? 0x5555555555555555ull : (0x5555555555555555ull & ((1ull << (2 * TEMP)) - 1));
-    __device__ static u64 load(const u8 *st, u64 n, u32 arr, u64 k) {
-        const u8 *p = st + ((u64)BASE + (u64)arr * BYTES) * n + k * BYTES;
-        if (BYTES == 8) return *(const u64 *)p;
-        if (BYTES == 4) return *(const u32 *)p;
-        if (BYTES == 2) return *(const u16 *)p;
-        return *p;
-    }
-    __device__ static void store(u8 *st, u64 n, u32 arr, u64 k, u64 v) {
-        u8 *p = st + ((u64)BASE + (u64)arr * BYTES) * n + k * BYTES;
-        if (BYTES == 8)
-            *(u64 *)p = v;
-        else if (BYTES == 4)
-            *(u32 *)p = (u32)v;
-        else if (BYTES == 2)
-            *(u16 *)p = (u16)v;
-        else
-            *p = (u8)v;
-    }
-};
+// ---- msb() carry tree (ABY3Engine.cpp:361-467) on dense bit arrays ------------------------------------------
+// The reference keeps one byte per bit and halves the vectors every round.  Here every share array (G0, G1, P0,
+// P1) of a level is ONE dense bit string: before the round with `temp` pairs per element, element k owns bits
+// [2*temp*k, 2*temp*(k+1)).  Pairs never straddle elements (2*temp is even), so a round is the same operation on
+// every aligned bit pair of the string, whatever the level: a lane takes 32 bits of each array, forms the 32
+// wire bytes they stand for (wire byte b of the whole message = bit b of the result string) and writes the 16
+// bits they leave in the next level.  `state` is 48*n bytes; levels alternate between two regions so that a round
+// never writes what another lane of the same launch still reads:
+//   level (pairs)    : 32   16    8    4    2    1    0 (result, 1 bit per element)
+//   region at byte   : 0    32n   0    32n  0    32n  0
+// and the four arrays of a level sit msb_stride() bytes apart.
+inline u64 msb_stride(u64 n, u32 temp) {
+    const u64 bits = temp ? 2ull * temp * n : n;
+    return (ceil_div(bits, 8) + 3) & ~3ull; // whole 32-bit words
+}
+inline u64 msb_base(u64 n, u32 temp) { return (temp == 32 || temp == 8 || temp == 2 || temp == 0) ? 0 : 32 * n; }
+
 // bits 0,2,4,.. of x moved to bits 0,1,2,..
-__device__ inline u64 compress_even(u64 x) {
-    x &= 0x5555555555555555ull;
-    x = (x | (x >> 1)) & 0x3333333333333333ull;
-    x = (x | (x >> 2)) & 0x0F0F0F0F0F0F0F0Full;
-    x = (x | (x >> 4)) & 0x00FF00FF00FF00FFull;
-    x = (x | (x >> 8)) & 0x0000FFFF0000FFFFull;
-    x = (x | (x >> 16)) & 0x00000000FFFFFFFFull;
+__device__ inline u32 compress_even(u32 x) {
+    x &= 0x55555555u;
+    x = (x | (x >> 1)) & 0x33333333u;
+    x = (x | (x >> 2)) & 0x0F0F0F0Fu;
+    x = (x | (x >> 4)) & 0x00FF00FFu;
+    x = (x | (x >> 8)) & 0x0000FFFFu;
     return x;
 }
-// this round's product share (ABY3Engine.cpp:397-414 + :253-256): bit 2m of `re` pairs (P[2m+1], G[2m]), bit 2m
-// of `ro` pairs (P[2m+1], P[2m]); shared AND = (x0&y0)^(x1&y0)^(x0&y1), no re-randomisation (:255)
-template <u32 TEMP> __device__ inline void msb_products(u64 g0, u64 g1, u64 p0, u64 p1, u64 &re, u64 &ro) {
-    constexpr u64 E = MsbLevel<TEMP>::EVEN;
-    const u64 po0 = (p0 >> 1) & E, po1 = (p1 >> 1) & E;
-    const u64 ge0 = g0 & E, ge1 = g1 & E, pe0 = p0 & E, pe1 = p1 & E;
-    re = (po0 & ge0) ^ (po1 & ge0) ^ (po0 & ge1);
-    ro = (po0 & pe0) ^ (po1 & pe0) ^ (po0 & pe1);
-}
-// wire bytes of the lane's NP pairs m0 .. m0+NP-1: byte 2j = even result bit, byte 2j+1 = odd result bit
-template <u32 NP> __device__ inline u64 msb_pack(u64 re, u64 ro, u32 m0) {
-    const u32 rb = (u32)(re >> (2 * m0)), ob = (u32)(ro >> (2 * m0));
-    u64 w = 0;
-#pragma unroll
-    for (u32 j = 0; j < NP; j++) {
-        w |= (u64)((rb >> (2 * j)) & 1u) << (16 * j);
-        w |= (u64)((ob >> (2 * j)) & 1u) << (16 * j + 8);
-    }
-    return w;
-}
-template <u32 NP> __device__ inline void msb_unpack(u64 w, u32 m0, u64 &re, u64 &ro) {
-    u64 rb = 0, ob = 0;
-#pragma unroll
-    for (u32 j = 0; j < NP; j++) {
-        rb |= ((w >> (16 * j)) & 1ull) << (2 * j);
-        ob |= ((w >> (16 * j + 8)) & 1ull) << (2 * j);
-    }
-    re = rb << (2 * m0);
-    ro = ob << (2 * m0);
-}
-template <u32 NP> __device__ inline void msb_store_piece(u8 *msg, u64 c, u64 w) {
-    if (NP == 4)
-        *(u64 *)(msg + 8 * c) = w;
-    else if (NP == 2)
-        *(u32 *)(msg + 4 * c) = (u32)w;
-    else
-        *(u16 *)(msg + 2 * c) = (u16)w;
-}
-template <u32 NP> __device__ inline u64 msb_load_piece(const u8 *msg, u64 c) {
-    if (NP == 4) return *(const u64 *)(msg + 8 * c);
-    if (NP == 2) return (u64) * (const u32 *)(msg + 4 * c);
-    return (u64) * (const u16 *)(msg + 2 * c);
+// 4 bits -> 4 bytes of 0/1 (the shifted copies of a 4-bit value do not overlap, so the product has no carries)
+__device__ inline u32 nibble_to_bytes(u32 x) { return (u32)__umul24(x & 0xFu, 0x204081u) & 0x01010101u; }
+// 4 bytes (bit 0 of each counts) -> 4 bits
+__device__ inline u32 bytes_to_nibble(u32 w) {
+    w &= 0x01010101u;
+    w |= w >> 7;
+    w |= w >> 14;
+    return w & 0xFu;
 }
 
-// before the round: every lane computes the element's product share and writes its piece of the message; the
-// element's first lane then writes share 0 of the next level (:424-425 with i = 0): G' = res_even ^ G_odd,
-// P' = res_odd, compacted.
-template <u32 TEMP> __global__ __launch_bounds__(256) void msb_round_pre_kernel(u8 *st, u64 n, u8 *__restrict__ msg) {
-    using In = MsbLevel<TEMP>;
-    using Out = MsbLevel<TEMP / 2>;
-    const u64 pieces = n * In::G;
-    for (u64 c = (u64)blockIdx.x * 256 + threadIdx.x; c < pieces; c += (u64)gridDim.x * 256) {
-        const u64 k = c / In::G;
-        const u32 q = (u32)(c % In::G);
-        const u64 g0 = In::load(st, n, 0, k), g1 = In::load(st, n, 1, k), p0 = In::load(st, n, 2, k), p1 = In::load(st, n, 3, k);
-        u64 re, ro;
-        msb_products<TEMP>(g0, g1, p0, p1, re, ro);
-        msb_store_piece<In::NP>(msg, c, msb_pack<In::NP>(re, ro, In::NP * q));
-        if (q == 0) {
-            Out::store(st, n, 0, k, compress_even(re ^ ((g0 >> 1) & In::EVEN)));
-            Out::store(st, n, 2, k, compress_even(ro));
+// Before the round (:397-414 + :253-256).  For the pair (2m, 2m+1): result bit 2m = share of P[2m+1] & G[2m],
+// result bit 2m+1 = share of P[2m+1] & P[2m], shared AND = (x0&y0)^(x1&y0)^(x0&y1) without re-randomisation (:255).
+// The result string goes out as one byte per bit; share 0 of the next level (:424-425 with i = 0) is
+// G' = result_even ^ G_odd, P' = result_odd, compacted.
+template <bool ALIGNED16>
+__global__ __launch_bounds__(256) void msb_round_pre_kernel(const u8 *__restrict__ in, u64 sin, u8 *__restrict__ out,
+                                                            u64 sout, u64 nbits, u8 *__restrict__ msg) {
+    constexpr u32 E = 0x55555555u;
+    const u64 words = (nbits + 31) / 32;
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < words; i += (u64)gridDim.x * 256) {
+        const u32 g0 = ((const u32 *)in)[i], g1 = ((const u32 *)(in + sin))[i];
+        const u32 p0 = ((const u32 *)(in + 2 * sin))[i], p1 = ((const u32 *)(in + 3 * sin))[i];
+        const u32 po0 = (p0 >> 1) & E, po1 = (p1 >> 1) & E;
+        const u32 ge0 = g0 & E, ge1 = g1 & E, pe0 = p0 & E, pe1 = p1 & E;
+        const u32 re = (po0 & ge0) ^ (po1 & ge0) ^ (po0 & ge1);
+        const u32 ro = (po0 & pe0) ^ (po1 & pe0) ^ (po0 & pe1);
+        const u32 r = re | (ro << 1);
+        u32 w[8];
+#pragma unroll
+        for (u32 q = 0; q < 8; q++) w[q] = nibble_to_bytes(r >> (4 * q));
+        u8 *dst = msg + 32 * i;
+        if (32 * i + 32 <= nbits) {
+            if (ALIGNED16) {
+                *(uint4 *)dst = make_uint4(w[0], w[1], w[2], w[3]);
+                *(uint4 *)(dst + 16) = make_uint4(w[4], w[5], w[6], w[7]);
+            } else {
+#pragma unroll
+                for (u32 q = 0; q < 4; q++) *(uint2 *)(dst + 8 * q) = make_uint2(w[2 * q], w[2 * q + 1]);
+            }
+        } else {
+            for (u64 t = 32 * i; t < nbits; t++) msg[t] = (u8)((r >> (t & 31)) & 1u);
+        }
+        if (2 * i + 2 <= sout) {
+            *(u16 *)(out + 2 * i) = (u16)compress_even(re ^ ((g0 >> 1) & E));
+            *(u16 *)(out + 2 * sout + 2 * i) = (u16)compress_even(ro);
         }
     }
 }
-// after the round (:416-428 with i = 1): msg = result[1] from the next party; the G lanes of an element OR
-// their pieces together and the first lane writes share 1 of the next level.
-template <u32 TEMP> __global__ __launch_bounds__(256) void msb_round_post_kernel(u8 *st, u64 n, const u8 *__restrict__ msg) {
-    using In = MsbLevel<TEMP>;
-    using Out = MsbLevel<TEMP / 2>;
-    const u64 pieces = n * In::G;
-    // every lane of a group must reach the shuffles: iterate on a wave-uniform trip count
-    const u64 stride = (u64)gridDim.x * 256;
-    for (u64 base = (u64)blockIdx.x * 256; base < pieces; base += stride) {
-        const u64 c = base + threadIdx.x;
-        const bool live = c < pieces; // pieces is a multiple of G, so a group is all-live or all-dead
-        const u64 k = live ? c / In::G : 0;
-        const u32 q = (u32)(c % In::G);
-        u64 re = 0, ro = 0;
-        if (live) msb_unpack<In::NP>(msb_load_piece<In::NP>(msg, c), In::NP * q, re, ro);
+// After the round (:416-428 with i = 1): msg = result[1] from the next party, packed back into bits; share 1 of the
+// next level is written.
+template <bool ALIGNED16>
+__global__ __launch_bounds__(256) void msb_round_post_kernel(const u8 *__restrict__ in, u64 sin, u8 *__restrict__ out,
+                                                             u64 sout, u64 nbits, const u8 *__restrict__ msg) {
+    constexpr u32 E = 0x55555555u;
+    const u64 words = (nbits + 31) / 32;
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < words; i += (u64)gridDim.x * 256) {
+        const u8 *src = msg + 32 * i;
+        u32 r = 0;
+        if (32 * i + 32 <= nbits) {
+            u32 w[8];
+            if (ALIGNED16) {
+                const uint4 a = *(const uint4 *)src, b = *(const uint4 *)(src + 16);
+                w[0] = a.x, w[1] = a.y, w[2] = a.z, w[3] = a.w, w[4] = b.x, w[5] = b.y, w[6] = b.z, w[7] = b.w;
+            } else {
 #pragma unroll
-        for (u32 d = 1; d < In::G; d <<= 1) { // groups are aligned runs of G lanes (G divides 64)
-            re |= __shfl_xor(re, (int)d, (int)In::G);
-            ro |= __shfl_xor(ro, (int)d, (int)In::G);
+                for (u32 q = 0; q < 4; q++) {
+                    const uint2 a = *(const uint2 *)(src + 8 * q);
+                    w[2 * q] = a.x, w[2 * q + 1] = a.y;
+                }
+            }
+#pragma unroll
+            for (u32 q = 0; q < 8; q++) r |= bytes_to_nibble(w[q]) << (4 * q);
+        } else {
+            for (u64 t = 32 * i; t < nbits; t++) r |= (u32)(msg[t] & 1) << (t & 31);
         }
-        if (live && q == 0) {
-            const u64 g1 = In::load(st, n, 1, k);
-            Out::store(st, n, 1, k, compress_even(re ^ ((g1 >> 1) & In::EVEN)));
-            Out::store(st, n, 3, k, compress_even(ro));
+        const u32 g1 = ((const u32 *)(in + sin))[i];
+        if (2 * i + 2 <= sout) {
+            *(u16 *)(out + sout + 2 * i) = (u16)compress_even((r & E) ^ ((g1 >> 1) & E));
+            *(u16 *)(out + 3 * sout + 2 * i) = (u16)compress_even((r >> 1) & E);
         }
     }
 }
@@ -308,51 +281,54 @@ int mpcx_aby3_msb_begin(mpcx_ctx *ctx, const int64_t *G0, const int64_t *G1, con
         state[3 * n + i] = (u64)P1[i] | top;
     });
 }
+static int msb_round_check(mpcx_ctx *ctx, const char *who, const void *state, const void *msg, uint64_t temp) {
+    MPCX_REQUIRE(state && msg, "%s: NULL pointer", who);
+    MPCX_REQUIRE(temp == 32 || temp == 16 || temp == 8 || temp == 4 || temp == 2 || temp == 1,
+                 "%s: temp must be one of 32,16,8,4,2,1", who);
+    MPCX_REQUIRE(((uintptr_t)msg & 7) == 0, "%s: the message must be 8-byte aligned", who);
+    return 0;
+}
 int mpcx_aby3_msb_round_pre(mpcx_ctx *ctx, uint64_t *state, uint64_t n, uint64_t temp, int8_t *msg_out) {
     if (n == 0) return 0;
-    MPCX_REQUIRE(state && msg_out, "mpcx_aby3_msb_round_pre: NULL pointer");
-    MPCX_REQUIRE(temp == 32 || temp == 16 || temp == 8 || temp == 4 || temp == 2 || temp == 1,
-                 "mpcx_aby3_msb_round_pre: temp must be one of 32,16,8,4,2,1");
-    MPCX_REQUIRE(((uintptr_t)msg_out & 7) == 0, "mpcx_aby3_msb_round_pre: msg_out must be 8-byte aligned");
+    MPCX_TRY(msb_round_check(ctx, "mpcx_aby3_msb_round_pre", state, msg_out, temp));
     ProfScope ps(ctx, PROF_MSB);
-#define MSB_PRE(T)                                                                                                     \
-    case T:                                                                                                            \
-        hipLaunchKernelGGL(msb_round_pre_kernel<T>, dim3(grid_for(n * MsbLevel<T>::G)), dim3(256), 0, ctx->stream,      \
-                           (u8 *)state, n, (u8 *)msg_out);                                                             \
-        break;
-    switch (temp) {
-        MSB_PRE(32) MSB_PRE(16) MSB_PRE(8) MSB_PRE(4) MSB_PRE(2) MSB_PRE(1)
-    }
-#undef MSB_PRE
+    u8 *st = (u8 *)state;
+    const u32 T = (u32)temp;
+    const u64 nbits = 2 * temp * n;
+    const dim3 grid(grid_for(ceil_div(nbits, 32))), block(256);
+    if (((uintptr_t)msg_out & 15) == 0)
+        hipLaunchKernelGGL(msb_round_pre_kernel<true>, grid, block, 0, ctx->stream, st + msb_base(n, T), msb_stride(n, T),
+                           st + msb_base(n, T / 2), msb_stride(n, T / 2), nbits, (u8 *)msg_out);
+    else
+        hipLaunchKernelGGL(msb_round_pre_kernel<false>, grid, block, 0, ctx->stream, st + msb_base(n, T), msb_stride(n, T),
+                           st + msb_base(n, T / 2), msb_stride(n, T / 2), nbits, (u8 *)msg_out);
     MPCX_LAUNCH_CHECK();
     return 0;
 }
 int mpcx_aby3_msb_round_post(mpcx_ctx *ctx, uint64_t *state, uint64_t n, uint64_t temp, const int8_t *msg_in) {
     if (n == 0) return 0;
-    MPCX_REQUIRE(state && msg_in, "mpcx_aby3_msb_round_post: NULL pointer");
-    MPCX_REQUIRE(temp == 32 || temp == 16 || temp == 8 || temp == 4 || temp == 2 || temp == 1,
-                 "mpcx_aby3_msb_round_post: temp must be one of 32,16,8,4,2,1");
-    MPCX_REQUIRE(((uintptr_t)msg_in & 7) == 0, "mpcx_aby3_msb_round_post: msg_in must be 8-byte aligned");
+    MPCX_TRY(msb_round_check(ctx, "mpcx_aby3_msb_round_post", state, msg_in, temp));
     ProfScope ps(ctx, PROF_MSB);
-#define MSB_POST(T)                                                                                                    \
-    case T:                                                                                                            \
-        hipLaunchKernelGGL(msb_round_post_kernel<T>, dim3(grid_for(n * MsbLevel<T>::G)), dim3(256), 0, ctx->stream,     \
-                           (u8 *)state, n, (const u8 *)msg_in);                                                        \
-        break;
-    switch (temp) {
-        MSB_POST(32) MSB_POST(16) MSB_POST(8) MSB_POST(4) MSB_POST(2) MSB_POST(1)
-    }
-#undef MSB_POST
+    u8 *st = (u8 *)state;
+    const u32 T = (u32)temp;
+    const u64 nbits = 2 * temp * n;
+    const dim3 grid(grid_for(ceil_div(nbits, 32))), block(256);
+    if (((uintptr_t)msg_in & 15) == 0)
+        hipLaunchKernelGGL(msb_round_post_kernel<true>, grid, block, 0, ctx->stream, st + msb_base(n, T), msb_stride(n, T),
+                           st + msb_base(n, T / 2), msb_stride(n, T / 2), nbits, (const u8 *)msg_in);
+    else
+        hipLaunchKernelGGL(msb_round_post_kernel<false>, grid, block, 0, ctx->stream, st + msb_base(n, T), msb_stride(n, T),
+                           st + msb_base(n, T / 2), msb_stride(n, T / 2), nbits, (const u8 *)msg_in);
     MPCX_LAUNCH_CHECK();
     return 0;
 }
 int mpcx_aby3_msb_final(mpcx_ctx *ctx, const uint64_t *state, const int64_t *P0_in, const int64_t *P1_in, uint64_t n,
                         int8_t *Z0, int8_t *Z1) {
     MPCX_REQUIRE((state && P0_in && P1_in && Z0 && Z1) || n == 0, "mpcx_aby3_msb_final: NULL pointer");
-    const u8 *st = (const u8 *)state;
-    return ew_launch(ctx, n, [=] __device__(u64 i) { // level 0: one byte per element and array
-        Z0[i] = (i8)((MsbLevel<0>::load(st, n, 0, i) & 1) ^ ((u64)P0_in[i] >> 63));
-        Z1[i] = (i8)((MsbLevel<0>::load(st, n, 1, i) & 1) ^ ((u64)P1_in[i] >> 63));
+    const u8 *g0 = (const u8 *)state + msb_base(n, 0), *g1 = g0 + msb_stride(n, 0);
+    return ew_launch(ctx, n, [=] __device__(u64 i) { // level 0: one bit per element and array
+        Z0[i] = (i8)(((g0[i >> 3] >> (i & 7)) & 1) ^ ((u64)P0_in[i] >> 63));
+        Z1[i] = (i8)(((g1[i >> 3] >> (i & 7)) & 1) ^ ((u64)P1_in[i] >> 63));
     });
 }
 

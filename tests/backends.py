@@ -411,6 +411,8 @@ class GpuBackend:
         return self._go("aby3_add_prepare_step2", _c(X0, np.int64), _c(X1, np.int64), _c(C0, np.int64),
                         _c(C1, np.int64), n, ("out", np.int64, n), ("out", np.int64, n), ("out", np.int64, n))
 
+    msb_msg_skew = 0
+
     class _Msb:
         def __init__(self, ctx, G0, G1, P0, P1):
             self.ctx, self.n = ctx, G0.size
@@ -421,13 +423,17 @@ class GpuBackend:
             ctx.sync()
 
         def round_pre(self, temp):
-            msg = self.ctx.empty(np.int8, self.n * 2 * temp)
+            k = GpuBackend.msb_msg_skew  # messages at this byte offset from an aligned allocation
+            buf = self.ctx.empty(np.int8, self.n * 2 * temp + k)
+            msg = buf.view(k, self.n * 2 * temp)
             self.ctx.call("aby3_msb_round_pre", self.state, self.n, temp, msg)
             self.ctx.sync()
             return msg.to_host()
 
         def round_post(self, temp, msg_in):
-            self.ctx.call("aby3_msb_round_post", self.state, self.n, temp, self.ctx.to_device(msg_in, np.int8))
+            k = GpuBackend.msb_msg_skew
+            buf = self.ctx.to_device(np.concatenate([np.zeros(k, np.int8), np.asarray(msg_in, np.int8)]), np.int8)
+            self.ctx.call("aby3_msb_round_post", self.state, self.n, temp, buf.view(k, msg_in.size))
             self.ctx.sync()
 
         def final(self):

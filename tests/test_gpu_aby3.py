@@ -190,3 +190,20 @@ def test_bad_shapes_are_rejected(gpu):
         gpu.ring_gemm(one, one, 0, 1, 1)
     with pytest.raises(MpcxError):
         gpu._go("aby3_msb_round_pre", np.zeros(4, np.uint64), 1, 3, ("out", np.int8, 8))
+
+
+@pytest.mark.parametrize("n", [1, 3, 13, 777])
+def test_aby3_msb_messages_at_8_byte_alignment(gpu, orc, n, monkeypatch):
+    """msb round messages that are 8- but not 16-byte aligned take the kernels' narrower load / store path."""
+    from backends import GpuBackend
+    monkeypatch.setattr(GpuBackend, "msb_msg_skew", 8)
+    X = prg_pops(25, 0, n)
+    res = []
+    for be in (gpu, orc):
+        w = pr.World(be)
+        Gs, Ps = pr.aby3_add_prepare(w, pr.aby3_share(w, X, n))
+        res.append((w, pr.aby3_msb(w, Gs, Ps)))
+    same_logs(res[0][0], res[1][0])
+    for j in range(3):
+        for i in range(2):
+            assert np.array_equal(res[0][1][j][i], res[1][1][j][i])
