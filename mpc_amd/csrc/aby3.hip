@@ -127,9 +127,8 @@ __global__ __launch_bounds__(256) void msb_round_post_kernel(const u8 *__restric
     }
 }
 
-inline u32 grid_for(u64 work) {
+inline u32 grid_for(u64 work) { // one item per lane unless the launch limit forces the kernels to loop
     u64 b = ceil_div(work, 256);
-    if (b > 16384) b = 16384; // msb rounds: 2048..65536 workgroups measure alike, an uncapped launch 12 % slower
     if (b > MPCX_MAX_GRID) b = MPCX_MAX_GRID;
     if (b == 0) b = 1;
     return (u32)b;
