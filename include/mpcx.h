@@ -129,7 +129,8 @@ int mpcx_aby3_add_prepare_step2(mpcx_ctx *ctx, const int64_t *X0, const int64_t 
 /* msb (:361-467), six rounds temp = 32,16,8,4,2,1.  The carry tree is kept as dense bit strings (bit
  * 2*temp*k + b of a level's string = the reference's byte k*2*temp+b) that halve every round; `state` is an
  * opaque scratch of 6*n 64-bit words owned by the caller for the duration of one msb.
- *  begin:      copies the inputs into state and applies :385-387 (G[63]=0, P[63]=1)
+ *  begin:      records the inputs; G0, G1, P0, P1 are read in place by the temp = 32 round (with :385-387,
+ *              G[63]=0, P[63]=1, applied on the fly) and must stay unchanged until its round_post has run
  *  round_pre:  builds this round's vecbool_mul product share (:397-414, :253-256), writes it to msg_out
  *              (2*temp bytes per element, the byte order of result[0]) and advances share 0 of the state
  *  round_post: msg_in = result[1] received from next; advances share 1 of the state (:416-428)

@@ -27,8 +27,10 @@ template <class F> int ew_launch(mpcx_ctx *ctx, u64 n, F f) {
 // bits they leave in the next level.  `state` is 48*n bytes; levels alternate between two regions so that a round
 // never writes what another lane of the same launch still reads:
 //   level (pairs)    : 32   16    8    4    2    1    0 (result, 1 bit per element)
-//   region at byte   : 0    32n   0    32n  0    32n  0
-// and the four arrays of a level sit msb_stride() bytes apart.
+//   region at byte   : --   32n   0    32n  0    32n  0
+// and the four arrays of a level sit msb_stride() bytes apart.  Level 32 is never stored: its rounds read the
+// caller's G / P words in place (their addresses are kept in the first 32 bytes of `state`) and apply
+// ABY3Engine.cpp:385-387 (G[63] = 0, P[63] = 1) on the fly.
 inline u64 msb_stride(u64 n, u32 temp) {
     const u64 bits = temp ? 2ull * temp * n : n;
     return (ceil_div(bits, 8) + 3) & ~3ull; // whole 32-bit words
@@ -58,14 +60,23 @@ __device__ inline u32 bytes_to_nibble(u32 w) {
 // result bit 2m+1 = share of P[2m+1] & P[2m], shared AND = (x0&y0)^(x1&y0)^(x0&y1) without re-randomisation (:255).
 // The result string goes out as one byte per bit; share 0 of the next level (:424-425 with i = 0) is
 // G' = result_even ^ G_odd, P' = result_odd, compacted.
-template <bool ALIGNED16>
+// word i of share array `arr` of the level a round reads.  FIRST (level 32): `in` holds the addresses of the
+// caller's G0, G1, P0, P1; bit 63 of every element (bit 31 of the odd words) is forced to 0 in G and 1 in P.
+template <bool FIRST> __device__ inline u32 msb_in_word(const u8 *in, u64 sin, u32 arr, u64 i) {
+    if (!FIRST) return ((const u32 *)(in + arr * sin))[i];
+    const u32 v = ((const u32 *)((const u64 *)in)[arr])[i];
+    if (!(i & 1)) return v;
+    return arr < 2 ? v & 0x7FFFFFFFu : v | 0x80000000u;
+}
+
+template <bool ALIGNED16, bool FIRST>
 __global__ __launch_bounds__(256) void msb_round_pre_kernel(const u8 *__restrict__ in, u64 sin, u8 *__restrict__ out,
                                                             u64 sout, u64 nbits, u8 *__restrict__ msg) {
     constexpr u32 E = 0x55555555u;
     const u64 words = (nbits + 31) / 32;
     for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < words; i += (u64)gridDim.x * 256) {
-        const u32 g0 = ((const u32 *)in)[i], g1 = ((const u32 *)(in + sin))[i];
-        const u32 p0 = ((const u32 *)(in + 2 * sin))[i], p1 = ((const u32 *)(in + 3 * sin))[i];
+        const u32 g0 = msb_in_word<FIRST>(in, sin, 0, i), g1 = msb_in_word<FIRST>(in, sin, 1, i);
+        const u32 p0 = msb_in_word<FIRST>(in, sin, 2, i), p1 = msb_in_word<FIRST>(in, sin, 3, i);
         const u32 po0 = (p0 >> 1) & E, po1 = (p1 >> 1) & E;
         const u32 ge0 = g0 & E, ge1 = g1 & E, pe0 = p0 & E, pe1 = p1 & E;
         const u32 re = (po0 & ge0) ^ (po1 & ge0) ^ (po0 & ge1);
@@ -94,7 +105,7 @@ __global__ __launch_bounds__(256) void msb_round_pre_kernel(const u8 *__restrict
 }
 // After the round (:416-428 with i = 1): msg = result[1] from the next party, packed back into bits; share 1 of the
 // next level is written.
-template <bool ALIGNED16>
+template <bool ALIGNED16, bool FIRST>
 __global__ __launch_bounds__(256) void msb_round_post_kernel(const u8 *__restrict__ in, u64 sin, u8 *__restrict__ out,
                                                              u64 sout, u64 nbits, const u8 *__restrict__ msg) {
     constexpr u32 E = 0x55555555u;
@@ -119,7 +130,7 @@ __global__ __launch_bounds__(256) void msb_round_post_kernel(const u8 *__restric
         } else {
             for (u64 t = 32 * i; t < nbits; t++) r |= (u32)(msg[t] & 1) << (t & 31);
         }
-        const u32 g1 = ((const u32 *)(in + sin))[i];
+        const u32 g1 = msb_in_word<FIRST>(in, sin, 1, i);
         if (2 * i + 2 <= sout) {
             *(u16 *)(out + sout + 2 * i) = (u16)compress_even((r & E) ^ ((g1 >> 1) & E));
             *(u16 *)(out + 3 * sout + 2 * i) = (u16)compress_even((r >> 1) & E);
@@ -271,14 +282,10 @@ int mpcx_aby3_add_prepare_step2(mpcx_ctx *ctx, const int64_t *X0, const int64_t 
 
 int mpcx_aby3_msb_begin(mpcx_ctx *ctx, const int64_t *G0, const int64_t *G1, const int64_t *P0, const int64_t *P1,
                         uint64_t n, uint64_t *state) {
-    MPCX_REQUIRE((G0 && G1 && P0 && P1 && state) || n == 0, "mpcx_aby3_msb_begin: NULL pointer");
-    const u64 top = 1ull << 63;
-    return ew_launch(ctx, n, [=] __device__(u64 i) { // level 32: four arrays of n 64-bit words
-        state[i] = (u64)G0[i] & ~top; // ABY3Engine.cpp:386
-        state[n + i] = (u64)G1[i] & ~top;
-        state[2 * n + i] = (u64)P0[i] | top; // :387
-        state[3 * n + i] = (u64)P1[i] | top;
-    });
+    if (n == 0) return 0;
+    MPCX_REQUIRE(G0 && G1 && P0 && P1 && state, "mpcx_aby3_msb_begin: NULL pointer");
+    const u64 a0 = (u64)(uintptr_t)G0, a1 = (u64)(uintptr_t)G1, a2 = (u64)(uintptr_t)P0, a3 = (u64)(uintptr_t)P1;
+    return ew_launch(ctx, 1, [=] __device__(u64) { state[0] = a0, state[1] = a1, state[2] = a2, state[3] = a3; });
 }
 static int msb_round_check(mpcx_ctx *ctx, const char *who, const void *state, const void *msg, uint64_t temp) {
     MPCX_REQUIRE(state && msg, "%s: NULL pointer", who);
@@ -287,20 +294,31 @@ static int msb_round_check(mpcx_ctx *ctx, const char *who, const void *state, co
     MPCX_REQUIRE(((uintptr_t)msg & 7) == 0, "%s: the message must be 8-byte aligned", who);
     return 0;
 }
+// launches KERNEL<16-byte aligned message, first level> for the round with `temp` pairs
+#define MSB_ROUND_LAUNCH(KERNEL, MSG)                                                                                  \
+    do {                                                                                                               \
+        u8 *st = (u8 *)state;                                                                                          \
+        const u32 T = (u32)temp;                                                                                       \
+        const u64 nbits = 2 * temp * n;                                                                                \
+        const dim3 grid(grid_for(ceil_div(nbits, 32))), block(256);                                                    \
+        const u8 *in = T == 32 ? st : st + msb_base(n, T);                                                             \
+        const u64 sin = msb_stride(n, T), sout = msb_stride(n, T / 2);                                                 \
+        u8 *out = st + msb_base(n, T / 2);                                                                             \
+        const bool a16 = ((uintptr_t)(MSG) & 15) == 0;                                                                 \
+        if (a16 && T == 32)                                                                                            \
+            hipLaunchKernelGGL((KERNEL<true, true>), grid, block, 0, ctx->stream, in, sin, out, sout, nbits, MSG);       \
+        else if (a16)                                                                                                  \
+            hipLaunchKernelGGL((KERNEL<true, false>), grid, block, 0, ctx->stream, in, sin, out, sout, nbits, MSG);      \
+        else if (T == 32)                                                                                              \
+            hipLaunchKernelGGL((KERNEL<false, true>), grid, block, 0, ctx->stream, in, sin, out, sout, nbits, MSG);      \
+        else                                                                                                           \
+            hipLaunchKernelGGL((KERNEL<false, false>), grid, block, 0, ctx->stream, in, sin, out, sout, nbits, MSG);     \
+    } while (0)
 int mpcx_aby3_msb_round_pre(mpcx_ctx *ctx, uint64_t *state, uint64_t n, uint64_t temp, int8_t *msg_out) {
     if (n == 0) return 0;
     MPCX_TRY(msb_round_check(ctx, "mpcx_aby3_msb_round_pre", state, msg_out, temp));
     ProfScope ps(ctx, PROF_MSB);
-    u8 *st = (u8 *)state;
-    const u32 T = (u32)temp;
-    const u64 nbits = 2 * temp * n;
-    const dim3 grid(grid_for(ceil_div(nbits, 32))), block(256);
-    if (((uintptr_t)msg_out & 15) == 0)
-        hipLaunchKernelGGL(msb_round_pre_kernel<true>, grid, block, 0, ctx->stream, st + msb_base(n, T), msb_stride(n, T),
-                           st + msb_base(n, T / 2), msb_stride(n, T / 2), nbits, (u8 *)msg_out);
-    else
-        hipLaunchKernelGGL(msb_round_pre_kernel<false>, grid, block, 0, ctx->stream, st + msb_base(n, T), msb_stride(n, T),
-                           st + msb_base(n, T / 2), msb_stride(n, T / 2), nbits, (u8 *)msg_out);
+    MSB_ROUND_LAUNCH(msb_round_pre_kernel, (u8 *)msg_out);
     MPCX_LAUNCH_CHECK();
     return 0;
 }
@@ -308,19 +326,11 @@ int mpcx_aby3_msb_round_post(mpcx_ctx *ctx, uint64_t *state, uint64_t n, uint64_
     if (n == 0) return 0;
     MPCX_TRY(msb_round_check(ctx, "mpcx_aby3_msb_round_post", state, msg_in, temp));
     ProfScope ps(ctx, PROF_MSB);
-    u8 *st = (u8 *)state;
-    const u32 T = (u32)temp;
-    const u64 nbits = 2 * temp * n;
-    const dim3 grid(grid_for(ceil_div(nbits, 32))), block(256);
-    if (((uintptr_t)msg_in & 15) == 0)
-        hipLaunchKernelGGL(msb_round_post_kernel<true>, grid, block, 0, ctx->stream, st + msb_base(n, T), msb_stride(n, T),
-                           st + msb_base(n, T / 2), msb_stride(n, T / 2), nbits, (const u8 *)msg_in);
-    else
-        hipLaunchKernelGGL(msb_round_post_kernel<false>, grid, block, 0, ctx->stream, st + msb_base(n, T), msb_stride(n, T),
-                           st + msb_base(n, T / 2), msb_stride(n, T / 2), nbits, (const u8 *)msg_in);
+    MSB_ROUND_LAUNCH(msb_round_post_kernel, (const u8 *)msg_in);
     MPCX_LAUNCH_CHECK();
     return 0;
 }
+#undef MSB_ROUND_LAUNCH
 int mpcx_aby3_msb_final(mpcx_ctx *ctx, const uint64_t *state, const int64_t *P0_in, const int64_t *P1_in, uint64_t n,
                         int8_t *Z0, int8_t *Z1) {
     MPCX_REQUIRE((state && P0_in && P1_in && Z0 && Z1) || n == 0, "mpcx_aby3_msb_final: NULL pointer");

@@ -238,10 +238,8 @@ void ABY3Engine::msb(const array<VecI64, 2> &Gj, const array<VecI64, 2> &Pj, arr
     assert(n == (size_t)Gj[1].size() && n == (size_t)Pj[0].size() && n == (size_t)Pj[1].size());
     Dev<int64_t> p0(gpu, Pj[0].data(), n), p1(gpu, Pj[1].data(), n);
     Dev<uint64_t> state(gpu, 6 * n);
-    {
-        Dev<int64_t> g0(gpu, Gj[0].data(), n), g1(gpu, Gj[1].data(), n);
-        GPU_OK(gpu, mpcx_aby3_msb_begin(gpu, g0, g1, p0, p1, n, state));
-    }
+    Dev<int64_t> g0(gpu, Gj[0].data(), n), g1(gpu, Gj[1].data(), n); // read in place by the first round
+    GPU_OK(gpu, mpcx_aby3_msb_begin(gpu, g0, g1, p0, p1, n, state));
     Dev<int8_t> msg(gpu, 64 * n);
     for (size_t temp = 32; temp != 0; temp /= 2) {
         const size_t bytes = 2 * temp * n;

@@ -417,9 +417,9 @@ class GpuBackend:
         def __init__(self, ctx, G0, G1, P0, P1):
             self.ctx, self.n = ctx, G0.size
             self.P0, self.P1 = ctx.to_device(P0, np.int64), ctx.to_device(P1, np.int64)
+            self.G0, self.G1 = ctx.to_device(G0, np.int64), ctx.to_device(G1, np.int64)  # read in place by round 32
             self.state = ctx.empty(np.uint64, 6 * self.n)
-            ctx.call("aby3_msb_begin", ctx.to_device(G0, np.int64), ctx.to_device(G1, np.int64), self.P0, self.P1,
-                     self.n, self.state)
+            ctx.call("aby3_msb_begin", self.G0, self.G1, self.P0, self.P1, self.n, self.state)
             ctx.sync()
 
         def round_pre(self, temp):
@@ -646,6 +646,7 @@ class ResidentBackend(GpuBackend):
     class _Msb:
         def __init__(self, be, G0, G1, P0, P1):
             self.be, self.n, self.P0, self.P1 = be, G0.size, P0, P1
+            self.G0, self.G1 = G0, G1  # read in place by round 32
             self.state = be.empty(np.uint64, 6 * self.n)
             be._run("aby3_msb_begin", G0, G1, P0, P1, self.n, self.state)
 
