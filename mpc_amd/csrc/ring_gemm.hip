@@ -36,17 +36,20 @@ __global__ __launch_bounds__(256) void split_limbs_kernel(const u64 *__restrict_
     const u32 tid = threadIdx.x;
     const u64 o0 = (u64)blockIdx.y * 64, k0 = (u64)blockIdx.x * 64;
     const bool k_fast = (sk == 1);
-#pragma unroll 4
+    // all 16 (or 32) loads of a lane are issued before the first is used: 32 KiB in flight per workgroup
+    u64 v[16];
+#pragma unroll
     for (u32 j = 0; j < 16; j++) {
         const u32 a = tid & 63, b = (tid >> 6) + 4 * j;
-        const u32 ko = k_fast ? a : b, oo = k_fast ? b : a;
-        const u64 o = o0 + oo, k = k0 + ko;
-        u64 v = 0;
-        if (o < O && k < K) {
-            v = src[o * so + k * sk];
-            if (src2) v += src2[o * so + k * sk];
-        }
-        tile[oo][ko] = v;
+        const u64 o = o0 + (k_fast ? b : a), k = k0 + (k_fast ? a : b);
+        const bool in = o < O && k < K;
+        v[j] = in ? src[o * so + k * sk] : 0;
+        if (src2 && in) v[j] += src2[o * so + k * sk];
+    }
+#pragma unroll
+    for (u32 j = 0; j < 16; j++) {
+        const u32 a = tid & 63, b = (tid >> 6) + 4 * j;
+        tile[k_fast ? b : a][k_fast ? a : b] = v[j];
     }
     __syncthreads();
     // thread -> (row oo, 16 consecutive k): a wave takes 32 rows x both 16-byte halves of one 32-byte K block, so
