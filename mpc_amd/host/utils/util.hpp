@@ -19,19 +19,35 @@ static const uint64_t L_1 = -1;
 using std::string;
 using std::vector;
 
+// The wire order is row-major, the matrices are stored column-major: both directions are a transposition, done
+// in 32 x 32 tiles so that neither side is walked with a large stride.
+static inline void cm_to_rm(const int64_t *cm, int64_t *rm, size_t rows, size_t cols) {
+    const size_t T = 32;
+    for (size_t j0 = 0; j0 < cols; j0 += T)
+        for (size_t i0 = 0; i0 < rows; i0 += T) {
+            const size_t j1 = j0 + T < cols ? j0 + T : cols, i1 = i0 + T < rows ? i0 + T : rows;
+            for (size_t j = j0; j < j1; j++)
+                for (size_t i = i0; i < i1; i++) rm[i * cols + j] = cm[j * rows + i];
+        }
+}
+static inline void rm_to_cm(const int64_t *rm, int64_t *cm, size_t rows, size_t cols) {
+    const size_t T = 32;
+    for (size_t j0 = 0; j0 < cols; j0 += T)
+        for (size_t i0 = 0; i0 < rows; i0 += T) {
+            const size_t j1 = j0 + T < cols ? j0 + T : cols, i1 = i0 + T < rows ? i0 + T : rows;
+            for (size_t j = j0; j < j1; j++)
+                for (size_t i = i0; i < i1; i++) cm[j * rows + i] = rm[i * cols + j];
+        }
+}
 static inline void matrix2string(const MatrixXl &input, string &output) {
     const size_t rows = input.rows(), cols = input.cols();
     output.resize(rows * cols * sizeof(int64_t));
-    int64_t *dst = (int64_t *)&output[0];
-    for (size_t j = 0; j < cols; j++)
-        for (size_t i = 0; i < rows; i++) dst[i * cols + j] = input(i, j);
+    if (rows && cols) cm_to_rm(input.data(), (int64_t *)&output[0], rows, cols);
 }
 static inline void string2matrix(const string &input, MatrixXl &output) {
     const size_t rows = output.rows(), cols = output.cols();
     assert(input.size() == rows * cols * sizeof(int64_t));
-    const int64_t *src = (const int64_t *)input.data();
-    for (size_t j = 0; j < cols; j++)
-        for (size_t i = 0; i < rows; i++) output(i, j) = src[i * cols + j];
+    if (rows && cols) rm_to_cm((const int64_t *)input.data(), output.data(), rows, cols);
 }
 static inline void vector2string(const vector<int64_t> &input, string &output) {
     output.assign((const char *)input.data(), input.size() * sizeof(int64_t));
@@ -52,14 +68,12 @@ static inline void string2vecZpshare(const string &input, vector<zpshare> &outpu
 static inline void matrix2vector(const MatrixXl &input, vector<int64_t> &output) {
     const size_t rows = input.rows(), cols = input.cols();
     output.resize(rows * cols);
-    for (size_t j = 0; j < cols; j++)
-        for (size_t i = 0; i < rows; i++) output[i * cols + j] = input(i, j);
+    if (rows && cols) cm_to_rm(input.data(), output.data(), rows, cols);
 }
 static inline void vector2matrix(const vector<int64_t> &input, MatrixXl &output) {
     const size_t rows = output.rows(), cols = output.cols();
     assert(input.size() == rows * cols);
-    for (size_t j = 0; j < cols; j++)
-        for (size_t i = 0; i < rows; i++) output(i, j) = input[i * cols + j];
+    if (rows && cols) rm_to_cm(input.data(), output.data(), rows, cols);
 }
 static inline void vecI642string(const VecI64 &input, string &output) {
     output.assign((const char *)input.data(), input.size() * sizeof(int64_t));
@@ -72,14 +86,12 @@ static inline void string2vecI64(const string &input, VecI64 &output) {
 static inline void vecI642matrix(const VecI64 &input, MatrixXl &output) {
     const size_t rows = output.rows(), cols = output.cols();
     assert((size_t)input.size() == rows * cols);
-    for (size_t j = 0; j < cols; j++)
-        for (size_t i = 0; i < rows; i++) output(i, j) = input[i * cols + j];
+    if (rows && cols) rm_to_cm(input.data(), output.data(), rows, cols);
 }
 static inline void matrix2vecI64(const MatrixXl &input, VecI64 &output) {
     const size_t rows = input.rows(), cols = input.cols();
     output.resize(rows * cols);
-    for (size_t j = 0; j < cols; j++)
-        for (size_t i = 0; i < rows; i++) output[i * cols + j] = input(i, j);
+    if (rows && cols) cm_to_rm(input.data(), output.data(), rows, cols);
 }
 static inline void vecbool2string(const vector<int8_t> &input, string &output) {
     output.assign((const char *)input.data(), input.size());
