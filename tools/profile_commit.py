@@ -1,4 +1,4 @@
-"""Development helper: copies the summaries of a tools_profile.sh run (gpurun_out/prof_<tag>/) into profiles/:
+"""Development helper: copies the summaries of a tools/profile.sh run (gpurun_out/prof_<tag>/) into profiles/:
 the rocprofv3 kernel stats CSV and a JSON digest of the PMC passes of the limb GEMM kernels."""
 import collections
 import csv

@@ -1,4 +1,4 @@
-"""Development helper: summarises a tools_profile.sh output directory (kernel stats + PMC passes)."""
+"""Development helper: summarises a tools/profile.sh output directory (kernel stats + PMC passes)."""
 import collections
 import csv
 import glob
