@@ -357,6 +357,12 @@ def main():
         else:
             dist.init_process_group("gloo")
 
+    if dist is not None and args.dist_backend == "nccl":
+        # bring the communicator up outside the timed region whatever --warmup is
+        probe = torch.zeros(world, dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(probe, probe[rank:rank + 1].clone())
+        torch.cuda.synchronize()
+
     from mpc_amd import Context
     ctx = Context(dev_index)
     ctx.call("set_stream", torch.cuda.current_stream().cuda_stream)
