@@ -59,6 +59,52 @@ __device__ inline u32 mod67_u16(u32 x) {
 //   w = b ? ((66 x + party) mod 2^16) % 67 : xm                                            (:561-562, :569-570)
 //   c = ((beta = 0 ? (66 x) % 67 + party b + party : 66 party b + x + party) + sum_w) mod 2^16 % 67   (:559, :567)
 // where (66 x) % 67 = (67 - xm) % 67 because the reference reduces that product before it is truncated.
+// SMALL: every x of the wavefront is below 67 (the protocol's domain): x % 67 = x and (66 x + party) % 67 =
+// (party - x) mod 67 need no division, and no sum leaves 16 bits.
+template <bool SMALL>
+__device__ inline void pc_piece(u32 pid, int mode, u32 q, u32 bits8, const u32 (&xw)[4], uint2 sb, u32 (&dw)[4]) {
+    u32 xk[8], xm[8], wv[8];
+    u32 tot = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        xk[j] = (j & 1) ? xw[j >> 1] >> 16 : xw[j >> 1] & 0xFFFF;
+        u32 w1;
+        if (SMALL) {
+            xm[j] = xk[j];
+            const i32 t = (i32)pid - (i32)xk[j];
+            w1 = (u32)(t + ((t >> 31) & (i32)P));
+        } else {
+            xm[j] = mod67_u16(xk[j]);
+            w1 = mod67_u16((mul24(xk[j], P - 1) + pid) & 0xFFFF);
+        }
+        wv[j] = ((bits8 >> j) & 1) ? w1 : xm[j];
+        tot += wv[j];
+    }
+    if (mode == 2) tot = 0;
+    // sum of W over all higher bit positions: suffix scan over the 8 lanes of the element
+    u32 incl = tot;
+#pragma unroll
+    for (u32 dlt = 1; dlt < 8; dlt <<= 1) {
+        const u32 t = __shfl_down(incl, dlt, 8);
+        if (q + dlt < 8) incl += t;
+    }
+    u32 run = incl - tot + pid; // W of the lanes above this one, plus the constant term of c
+    const u32 add1 = mode == 0 ? pid : (P - 1) * pid; // coefficient of the bit
+#pragma unroll
+    for (int j = 7; j >= 0; j--) {
+        const u32 b = (bits8 >> j) & 1;
+        // (66 x) % 67 = (67 - xm) % 67; the unreduced 67 - xm gives the same c
+        const u32 pre = mode == 0 ? P - xm[j] : xk[j];
+        u32 t = pre + run + mul24(b, add1);
+        if (!SMALL) t &= 0xFFFF;
+        const u32 ck = mod67_u16(t);
+        run += wv[j];
+        const u32 sk = ((j < 4 ? sb.x : sb.y) >> (8 * (j & 3))) & 0xFF;
+        const u32 dk = mod67_u16(mul24(sk, ck)); // :589-590 (both factors are below 67)
+        dw[j >> 1] |= dk << (16 * (j & 1));
+    }
+}
+
 __global__ __launch_bounds__(256) void pc_party_kernel(int party, int variant, const uint4 *__restrict__ xbits, const i8 *__restrict__ beta,
                                                        const i64 *__restrict__ r, const u64 *__restrict__ S,
                                                        const u64 *__restrict__ U, u64 n, uint4 *__restrict__ d_out) {
@@ -70,13 +116,13 @@ __global__ __launch_bounds__(256) void pc_party_kernel(int party, int variant, c
         const bool live = c < pieces;
         const u64 i = live ? c >> 3 : 0;
         const u32 q = (u32)(c & 7);
-        u16x8 x{}, d{};
+        u32 xw[4] = {0, 0, 0, 0}, dw[4] = {0, 0, 0, 0};
         uint2 sb = make_uint2(0, 0); // the 8 s bytes of this lane's positions
         u64 rv = 0;
         int bt = 0;
         if (live) {
             const uint4 xv = xbits[c];
-            x.w[0] = xv.x, x.w[1] = xv.y, x.w[2] = xv.z, x.w[3] = xv.w;
+            xw[0] = xv.x, xw[1] = xv.y, xw[2] = xv.z, xw[3] = xv.w;
             sb = ((const uint2 *)S)[c];
             rv = (u64)r[i];
             bt = beta[i];
@@ -84,38 +130,18 @@ __global__ __launch_bounds__(256) void pc_party_kernel(int party, int variant, c
         const int mode = (bt == 0) ? 0 : ((variant == 1 || (bt == 1 && rv != ~0ull)) ? 1 : 2);
         // the 8 bits of r (mode 0) or r + 1 (mode 1) this lane works on
         const u32 bits8 = (u32)(((mode == 0 ? rv : rv + 1) >> (8 * q)) & 0xFF);
-        u32 xm[8], wv[8];
-        u32 tot = 0;
+        // any 16-bit x above 66?  (above 127, or below 128 with x + 61 reaching 128)
+        u32 big = 0;
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const u32 xk = x.get(j);
-            xm[j] = mod67_u16(xk);
-            const u32 w1 = mod67_u16((mul24(xk, P - 1) + pid) & 0xFFFF);
-            wv[j] = ((bits8 >> j) & 1) ? w1 : xm[j];
-            tot += wv[j];
-        }
-        if (mode == 2) tot = 0;
-        // sum of W over all higher bit positions: suffix scan over the 8 lanes of the element
-        u32 incl = tot;
-#pragma unroll
-        for (u32 dlt = 1; dlt < 8; dlt <<= 1) {
-            const u32 t = __shfl_down(incl, dlt, 8);
-            if (q + dlt < 8) incl += t;
-        }
-        u32 run = incl - tot; // W of the lanes above this one
-        const u32 add1 = mode == 0 ? pid : (P - 1) * pid; // coefficient of the bit
-#pragma unroll
-        for (int j = 7; j >= 0; j--) {
-            const u32 b = (bits8 >> j) & 1;
-            const u32 pre = mode == 0 ? (xm[j] ? P - xm[j] : 0u) : x.get(j);
-            const u32 ck = mod67_u16((pre + (b ? add1 : 0u) + pid + run) & 0xFFFF);
-            run += wv[j];
-            const u32 sk = ((j < 4 ? sb.x : sb.y) >> (8 * (j & 3))) & 0xFF;
-            d.set(j, mod67_u16(mul24(sk, ck))); // :589-590 (both factors are below 67)
-        }
+        for (int k = 0; k < 4; k++) big |= (xw[k] & 0xFF80FF80u) | ((xw[k] + 0x003D003Du) & 0x00800080u);
+        if (__any(big != 0))
+            pc_piece<false>(pid, mode, q, bits8, xw, sb, dw);
+        else
+            pc_piece<true>(pid, mode, q, bits8, xw, sb, dw);
         if (__any(mode == 2)) { // beta = 1 and r = -1 (:574-584): c comes from u alone
             uint2 ub = make_uint2(0, 0);
             if (mode == 2 && live) ub = ((const uint2 *)U)[c];
+            u32 d2[4] = {0, 0, 0, 0};
 #pragma unroll
             for (int j = 0; j < 8; j++) {
                 const u32 uk = ((j < 4 ? ub.x : ub.y) >> (8 * (j & 3))) & 0xFF;
@@ -125,10 +151,14 @@ __global__ __launch_bounds__(256) void pc_party_kernel(int party, int variant, c
                 else
                     ck = pid == 0 ? uk : P - uk; // :582
                 const u32 sk = ((j < 4 ? sb.x : sb.y) >> (8 * (j & 3))) & 0xFF;
-                if (mode == 2) d.set(j, mod67_u16(mul24(sk, ck)));
+                d2[j >> 1] |= mod67_u16(mul24(sk, ck)) << (16 * (j & 1));
+            }
+            if (mode == 2) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) dw[k] = d2[k];
             }
         }
-        if (live) d_out[c] = make_uint4(d.w[0], d.w[1], d.w[2], d.w[3]);
+        if (live) d_out[c] = make_uint4(dw[0], dw[1], dw[2], dw[3]);
     }
 }
 
