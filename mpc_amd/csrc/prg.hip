@@ -154,17 +154,25 @@ int mpcx_prg_table(mpcx_ctx *ctx, u64 seed, u64 lcg, u64 t_end, const PrgCk **de
     }
     const u64 need = t_end / PRG_CK + 1; // checkpoints 0 .. floor(t_end/PRG_CK)
     if (T.host.size() < need) {
-        T.host.reserve(need);
+        // A pop stream is consumed a little further by every call: walk some way past the request (1/8 more,
+        // between 4 Ki and 64 Ki checkpoints) so that the table -- and its device copy -- grows once in many calls.
+        u64 ahead = need / 8;
+        ahead = ahead < 4096 ? 4096 : ahead > 65536 ? 65536 : ahead;
+        const u64 want = need + ahead;
+        T.host.reserve(want);
         PrgCk c = T.host.back();
-        while (T.host.size() < need) {
+        while (T.host.size() < want) {
             for (u64 i = 0; i < PRG_CK; i++) prv_step(c.seed, c.lcg, c.hash);
             T.host.push_back(c);
         }
     }
     if (T.dev_count < need) {
         MPCX_HIP(hipSetDevice(ctx->device));
-        if (T.dev_cap < need) {
-            u64 cap = need + need / 4 + 1024;
+        const u64 have = T.host.size();
+        if (T.dev_cap < have) {
+            u64 room = have / 2; // spare room for later growth without another reallocation
+            room = room < 4096 ? 4096 : room > (1u << 20) ? (1u << 20) : room;
+            const u64 cap = have + room;
             PrgCk *nd = nullptr;
             MPCX_HIP(hipMalloc((void **)&nd, cap * sizeof(PrgCk)));
             if (T.dev) T.retired.push_back(T.dev);
@@ -172,9 +180,9 @@ int mpcx_prg_table(mpcx_ctx *ctx, u64 seed, u64 lcg, u64 t_end, const PrgCk **de
             T.dev_cap = cap;
             T.dev_count = 0;
         }
-        MPCX_HIP(hipMemcpy(T.dev + T.dev_count, T.host.data() + T.dev_count, (need - T.dev_count) * sizeof(PrgCk),
+        MPCX_HIP(hipMemcpy(T.dev + T.dev_count, T.host.data() + T.dev_count, (have - T.dev_count) * sizeof(PrgCk),
                            hipMemcpyHostToDevice));
-        T.dev_count = need;
+        T.dev_count = have;
     }
     *dev = T.dev;
     return 0;
