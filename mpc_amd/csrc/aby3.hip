@@ -3,6 +3,7 @@
 // kept as packed words that halve in width every round, and only the wire messages are expanded to
 // one byte per bit.
 #include "mpcx_internal.h"
+#include "prg_map.h"
 
 namespace {
 
@@ -360,18 +361,35 @@ int mpcx_aby3_trunc_local(mpcx_ctx *ctx, int party, const int64_t *X0, const int
     });
 }
 
-// ---- bit_inject: the PRG words of the call are regenerated into scratch (s01: 6n or 3n words, other
-// stream: 3n words), then one streaming pass forms the messages / the output shares.
-// A call works on elements [i0, i0 + n) of a vector of n_total elements.  The reference lays the words of a
-// stream out per whole vector (ABY3Engine.cpp:539-558): C[n_total], then n_total (W_0, W_1) pairs, and on s01
-// the same again for the second OT.  The scratch copy keeps that order with sections of n.
+// ---- bit_inject.  A call works on elements [i0, i0 + n) of a vector of n_total elements.  The reference lays the
+// words of a stream out per whole vector (ABY3Engine.cpp:539-558): C[n_total], then n_total (W_0, W_1) pairs, and on
+// s01 the same again for the second OT.  Every use of those words is fused with their regeneration (prg_map.h):
+//   * masks C: one word per element; the two C words an element needs come from two streams in one pass;
+//   * W pairs: element e owns words 2e, 2e+1 of its section; word index w is (e = w >> 1, t = w & 1).
+// The two plain OT messages M_0, M_1 of a sender go through 16*n bytes of scratch between the passes.
 } // extern "C"
-// sections C | W pairs of one OT, `base` = stream word of C[0] of the whole vector
-static int bi_fill_ot(mpcx_ctx *ctx, u64 seed, u64 base, u64 n_total, u64 i0, u64 n, u64 *dst) {
-    if (n == n_total) return prg_fill_words(ctx, seed, 0, base, 3 * n, 1, (i64 *)dst, nullptr);
-    MPCX_TRY(prg_fill_words(ctx, seed, 0, base + i0, n, 1, (i64 *)dst, nullptr));
-    return prg_fill_words(ctx, seed, 0, base + n_total + 2 * i0, 2 * n, 1, (i64 *)(dst + n), nullptr);
+namespace {
+struct BiGeom {
+    u64 nt, i0, n;
+    // stream word of C[i0] / of the pair of element i0, for the OT whose section starts `base` words into the stream
+    u64 c(u64 base) const { return base + i0; }
+    u64 w(u64 base) const { return base + nt + 2 * i0; }
+};
+// out[t * n + e] = M[t * n + e] ^ W_t[e]: both masked OT messages of a sender from one pass over its pair words
+int bi_mask_pairs(mpcx_ctx *ctx, u64 seed, u64 t_first, u64 n, const u64 *M, u64 *out) {
+    return prg_map1(ctx, seed, t_first, 2 * n, [=] __device__(u64 w, u64 v) {
+        const u64 k = (w & 1) * n + (w >> 1);
+        out[k] = M[k] ^ v;
+    });
 }
+// out[e] = W_b[e] with b = (sel[e] == 1): the helper's word for the receiver
+int bi_select_pairs(mpcx_ctx *ctx, u64 seed, u64 t_first, u64 n, const i8 *sel, u64 *out) {
+    return prg_map1(ctx, seed, t_first, 2 * n, [=] __device__(u64 w, u64 v) {
+        const u64 e = w >> 1;
+        if ((u64)(sel[e] == 1) == (w & 1)) out[e] = v;
+    });
+}
+} // namespace
 #define BI_RANGE_CHECK(name)                                                                                           \
     MPCX_REQUIRE(i0 <= n_total && n <= n_total - i0, name ": elements [%llu, +%llu) outside a vector of %llu",          \
                  (unsigned long long)i0, (unsigned long long)n, (unsigned long long)n_total)
@@ -382,24 +400,22 @@ int mpcx_aby3_bit_inject_p0_pre(mpcx_ctx *ctx, const int64_t *A0, const int8_t *
     BI_RANGE_CHECK("mpcx_aby3_bit_inject_p0_pre");
     if (n == 0) return 0;
     MPCX_REQUIRE(A0 && B0 && B1 && to_p1 && to_p2, "mpcx_aby3_bit_inject_p0_pre: NULL pointer");
+    const BiGeom G{n_total, i0, n};
+    const u64 b01 = PRG_POP_T0 + pop01, b20 = PRG_POP_T0 + pop20;
     void *ws;
-    MPCX_TRY(mpcx_ws(ctx, 72 * n, &ws));
-    u64 *s01 = (u64 *)ws, *s20 = s01 + 6 * n;
-    MPCX_TRY(bi_fill_ot(ctx, seed01, PRG_POP_T0 + pop01, n_total, i0, n, s01));
-    MPCX_TRY(bi_fill_ot(ctx, seed01, PRG_POP_T0 + pop01 + 3 * n_total, n_total, i0, n, s01 + 3 * n));
-    MPCX_TRY(bi_fill_ot(ctx, seed20, PRG_POP_T0 + pop20, n_total, i0, n, s20));
-    u64 *m1 = (u64 *)to_p1, *m2 = (u64 *)to_p2;
-    return ew_launch(ctx, n, [=] __device__(u64 i) {
-        const u64 cc = s01[i] + s20[i];
-        const u64 a = (u64)A0[i];
-        const i64 t = (i64)(B0[i] ^ B1[i]);
-        const u64 M0 = (u64)(0 ^ t) * a - cc, M1 = (u64)(1 ^ t) * a - cc; // ABY3Engine.cpp:547-548
-        m1[i] = M0 ^ s20[n + 2 * i];
-        m1[n + i] = M1 ^ s20[n + 2 * i + 1];
-        m2[i] = M0 ^ s01[n + 2 * i];
-        m2[n + i] = M1 ^ s01[n + 2 * i + 1];
-        m2[2 * n + i] = B0[i] == 1 ? s01[4 * n + 2 * i + 1] : s01[4 * n + 2 * i]; // :603
-    });
+    MPCX_TRY(mpcx_ws(ctx, 16 * n, &ws));
+    u64 *M = (u64 *)ws;
+    // M_t = (t ^ b_x ^ b_y) a - c - c' with c + c' = C01 + C02 (ABY3Engine.cpp:547-548)
+    MPCX_TRY(prg_map2(ctx, seed01, G.c(b01), seed20, G.c(b20), n, [] __device__(u64 a, u64 b) { return a + b; },
+                      [=] __device__(u64 i, u64 cc) {
+                          const u64 a = (u64)A0[i];
+                          const i64 t = (i64)(B0[i] ^ B1[i]);
+                          M[i] = (u64)(0 ^ t) * a - cc;
+                          M[n + i] = (u64)(1 ^ t) * a - cc;
+                      }));
+    MPCX_TRY(bi_mask_pairs(ctx, seed20, G.w(b20), n, M, (u64 *)to_p1));                  // ^ W02
+    MPCX_TRY(bi_mask_pairs(ctx, seed01, G.w(b01), n, M, (u64 *)to_p2));                  // ^ W01
+    return bi_select_pairs(ctx, seed01, G.w(b01 + 3 * n_total), n, B0, (u64 *)to_p2 + 2 * n); // W10_b (:603)
 }
 int mpcx_aby3_bit_inject_p0_post(mpcx_ctx *ctx, const int8_t *B0, uint64_t n_total, uint64_t i0, uint64_t n,
                                  uint64_t seed01, uint64_t pop01, uint64_t seed20, uint64_t pop20,
@@ -407,19 +423,16 @@ int mpcx_aby3_bit_inject_p0_post(mpcx_ctx *ctx, const int8_t *B0, uint64_t n_tot
     BI_RANGE_CHECK("mpcx_aby3_bit_inject_p0_post");
     if (n == 0) return 0;
     MPCX_REQUIRE(B0 && from_p1 && from_p2 && C0 && C1, "mpcx_aby3_bit_inject_p0_post: NULL pointer");
-    void *ws;
-    MPCX_TRY(mpcx_ws(ctx, 24 * n, &ws));
-    u64 *c01 = (u64 *)ws, *c10 = c01 + n, *c02 = c10 + n;
-    MPCX_TRY(prg_fill_words(ctx, seed01, 0, PRG_POP_T0 + pop01 + i0, n, 1, (i64 *)c01, nullptr));
-    MPCX_TRY(prg_fill_words(ctx, seed01, 0, PRG_POP_T0 + pop01 + 3 * n_total + i0, n, 1, (i64 *)c10, nullptr));
-    MPCX_TRY(prg_fill_words(ctx, seed20, 0, PRG_POP_T0 + pop20 + i0, n, 1, (i64 *)c02, nullptr));
+    const BiGeom G{n_total, i0, n};
+    const u64 b01 = PRG_POP_T0 + pop01, b20 = PRG_POP_T0 + pop20;
     const u64 *f1 = (const u64 *)from_p1, *f2 = (const u64 *)from_p2;
     u64 *o0 = (u64 *)C0, *o1 = (u64 *)C1;
-    return ew_launch(ctx, n, [=] __device__(u64 i) {
+    MPCX_TRY(prg_map1(ctx, seed20, G.c(b20), n, [=] __device__(u64 i, u64 c02) {
         const u64 a12 = (B0[i] == 1 ? f1[n + i] : f1[i]) ^ f2[i]; // :660
-        o0[i] = c02[i] + a12;                                      // A0j[0] + A12j[0]
-        o1[i] = c01[i] + c10[i];                                   // A0j[1] + A12j[1]
-    });
+        o0[i] = c02 + a12;                                        // A0j[0] + A12j[0]
+    }));
+    return prg_map2(ctx, seed01, G.c(b01), seed01, G.c(b01 + 3 * n_total), n, [] __device__(u64 a, u64 b) { return a + b; },
+                    [=] __device__(u64 i, u64 v) { o1[i] = v; }); // A0j[1] + A12j[1] = C01 + C10
 }
 int mpcx_aby3_bit_inject_p1_pre(mpcx_ctx *ctx, const int64_t *A0, const int64_t *A1, const int8_t *B0,
                                 const int8_t *B1, uint64_t n_total, uint64_t i0, uint64_t n, uint64_t seed01,
@@ -427,24 +440,22 @@ int mpcx_aby3_bit_inject_p1_pre(mpcx_ctx *ctx, const int64_t *A0, const int64_t 
     BI_RANGE_CHECK("mpcx_aby3_bit_inject_p1_pre");
     if (n == 0) return 0;
     MPCX_REQUIRE(A0 && A1 && B0 && B1 && to_p0 && to_p2, "mpcx_aby3_bit_inject_p1_pre: NULL pointer");
+    const BiGeom G{n_total, i0, n};
+    const u64 b01 = PRG_POP_T0 + pop01, b12 = PRG_POP_T0 + pop12;
     void *ws;
-    MPCX_TRY(mpcx_ws(ctx, 72 * n, &ws));
-    u64 *s01 = (u64 *)ws, *s12 = s01 + 6 * n;
-    MPCX_TRY(bi_fill_ot(ctx, seed01, PRG_POP_T0 + pop01, n_total, i0, n, s01));
-    MPCX_TRY(bi_fill_ot(ctx, seed01, PRG_POP_T0 + pop01 + 3 * n_total, n_total, i0, n, s01 + 3 * n));
-    MPCX_TRY(bi_fill_ot(ctx, seed12, PRG_POP_T0 + pop12, n_total, i0, n, s12));
-    u64 *m0 = (u64 *)to_p0, *m2 = (u64 *)to_p2;
-    return ew_launch(ctx, n, [=] __device__(u64 i) {
-        const u64 cc = s01[3 * n + i] + s12[i]; // C10 + C12
-        const u64 a = (u64)A0[i] + (u64)A1[i];
-        const i64 t = (i64)(B0[i] ^ B1[i]);
-        const u64 M0 = (u64)(0 ^ t) * a - cc, M1 = (u64)(1 ^ t) * a - cc; // :751-752
-        m2[i] = B1[i] == 1 ? s01[n + 2 * i + 1] : s01[n + 2 * i];         // :722
-        m2[n + i] = M0 ^ s01[4 * n + 2 * i];
-        m2[2 * n + i] = M1 ^ s01[4 * n + 2 * i + 1];
-        m0[i] = M0 ^ s12[n + 2 * i];
-        m0[n + i] = M1 ^ s12[n + 2 * i + 1];
-    });
+    MPCX_TRY(mpcx_ws(ctx, 16 * n, &ws));
+    u64 *M = (u64 *)ws;
+    // M_t = (t ^ b_x ^ b_y)(a_1 + a_2) - C10 - C12 (:751-752)
+    MPCX_TRY(prg_map2(ctx, seed01, G.c(b01 + 3 * n_total), seed12, G.c(b12), n, [] __device__(u64 a, u64 b) { return a + b; },
+                      [=] __device__(u64 i, u64 cc) {
+                          const u64 a = (u64)A0[i] + (u64)A1[i];
+                          const i64 t = (i64)(B0[i] ^ B1[i]);
+                          M[i] = (u64)(0 ^ t) * a - cc;
+                          M[n + i] = (u64)(1 ^ t) * a - cc;
+                      }));
+    MPCX_TRY(bi_select_pairs(ctx, seed01, G.w(b01), n, B1, (u64 *)to_p2));                        // W01_b (:722)
+    MPCX_TRY(bi_mask_pairs(ctx, seed01, G.w(b01 + 3 * n_total), n, M, (u64 *)to_p2 + n));         // ^ W10
+    return bi_mask_pairs(ctx, seed12, G.w(b12), n, M, (u64 *)to_p0);                              // ^ W12
 }
 int mpcx_aby3_bit_inject_p1_post(mpcx_ctx *ctx, const int8_t *B1, uint64_t n_total, uint64_t i0, uint64_t n,
                                  uint64_t seed01, uint64_t pop01, uint64_t seed12, uint64_t pop12,
@@ -452,18 +463,15 @@ int mpcx_aby3_bit_inject_p1_post(mpcx_ctx *ctx, const int8_t *B1, uint64_t n_tot
     BI_RANGE_CHECK("mpcx_aby3_bit_inject_p1_post");
     if (n == 0) return 0;
     MPCX_REQUIRE(B1 && from_p0 && from_p2 && C0 && C1, "mpcx_aby3_bit_inject_p1_post: NULL pointer");
-    void *ws;
-    MPCX_TRY(mpcx_ws(ctx, 24 * n, &ws));
-    u64 *c01 = (u64 *)ws, *c10 = c01 + n, *c12 = c10 + n;
-    MPCX_TRY(prg_fill_words(ctx, seed01, 0, PRG_POP_T0 + pop01 + i0, n, 1, (i64 *)c01, nullptr));
-    MPCX_TRY(prg_fill_words(ctx, seed01, 0, PRG_POP_T0 + pop01 + 3 * n_total + i0, n, 1, (i64 *)c10, nullptr));
-    MPCX_TRY(prg_fill_words(ctx, seed12, 0, PRG_POP_T0 + pop12 + i0, n, 1, (i64 *)c12, nullptr));
+    const BiGeom G{n_total, i0, n};
+    const u64 b01 = PRG_POP_T0 + pop01, b12 = PRG_POP_T0 + pop12;
     const u64 *f0 = (const u64 *)from_p0, *f2 = (const u64 *)from_p2;
     u64 *o0 = (u64 *)C0, *o1 = (u64 *)C1;
-    return ew_launch(ctx, n, [=] __device__(u64 i) {
+    MPCX_TRY(prg_map2(ctx, seed01, G.c(b01), seed01, G.c(b01 + 3 * n_total), n, [] __device__(u64 a, u64 b) { return a + b; },
+                      [=] __device__(u64 i, u64 v) { o0[i] = v; })); // A0j[0] + A12j[0] = C01 + C10
+    return prg_map1(ctx, seed12, G.c(b12), n, [=] __device__(u64 i, u64 c12) {
         const u64 a0 = (B1[i] == 1 ? f0[n + i] : f0[i]) ^ f2[i]; // :811
-        o0[i] = c01[i] + c10[i];                                  // A0j[0] + A12j[0]
-        o1[i] = a0 + c12[i];                                      // A0j[1] + A12j[1]
+        o1[i] = a0 + c12;                                        // A0j[1] + A12j[1]
     });
 }
 int mpcx_aby3_bit_inject_p2_pre(mpcx_ctx *ctx, const int8_t *B0, const int8_t *B1, uint64_t n_total, uint64_t i0,
@@ -472,16 +480,9 @@ int mpcx_aby3_bit_inject_p2_pre(mpcx_ctx *ctx, const int8_t *B0, const int8_t *B
     BI_RANGE_CHECK("mpcx_aby3_bit_inject_p2_pre");
     if (n == 0) return 0;
     MPCX_REQUIRE(B0 && B1 && to_p0 && to_p1, "mpcx_aby3_bit_inject_p2_pre: NULL pointer");
-    void *ws;
-    MPCX_TRY(mpcx_ws(ctx, 32 * n, &ws));
-    u64 *w02 = (u64 *)ws, *w12 = w02 + 2 * n;
-    MPCX_TRY(prg_fill_words(ctx, seed20, 0, PRG_POP_T0 + pop20 + n_total + 2 * i0, 2 * n, 1, (i64 *)w02, nullptr));
-    MPCX_TRY(prg_fill_words(ctx, seed12, 0, PRG_POP_T0 + pop12 + n_total + 2 * i0, 2 * n, 1, (i64 *)w12, nullptr));
-    u64 *m0 = (u64 *)to_p0, *m1 = (u64 *)to_p1;
-    return ew_launch(ctx, n, [=] __device__(u64 i) {
-        m1[i] = B0[i] == 1 ? w02[2 * i + 1] : w02[2 * i]; // :888
-        m0[i] = B1[i] == 1 ? w12[2 * i + 1] : w12[2 * i]; // :922
-    });
+    const BiGeom G{n_total, i0, n};
+    MPCX_TRY(bi_select_pairs(ctx, seed20, G.w(PRG_POP_T0 + pop20), n, B0, (u64 *)to_p1)); // W02_b (:888)
+    return bi_select_pairs(ctx, seed12, G.w(PRG_POP_T0 + pop12), n, B1, (u64 *)to_p0);    // W12_b (:922)
 }
 int mpcx_aby3_bit_inject_p2_post(mpcx_ctx *ctx, const int8_t *B0, const int8_t *B1, uint64_t n_total, uint64_t i0,
                                  uint64_t n, uint64_t seed20, uint64_t pop20, uint64_t seed12, uint64_t pop12,
@@ -489,18 +490,16 @@ int mpcx_aby3_bit_inject_p2_post(mpcx_ctx *ctx, const int8_t *B0, const int8_t *
     BI_RANGE_CHECK("mpcx_aby3_bit_inject_p2_post");
     if (n == 0) return 0;
     MPCX_REQUIRE(B0 && B1 && from_p0 && from_p1 && C0 && C1, "mpcx_aby3_bit_inject_p2_post: NULL pointer");
-    void *ws;
-    MPCX_TRY(mpcx_ws(ctx, 16 * n, &ws));
-    u64 *c02 = (u64 *)ws, *c12 = c02 + n;
-    MPCX_TRY(prg_fill_words(ctx, seed20, 0, PRG_POP_T0 + pop20 + i0, n, 1, (i64 *)c02, nullptr));
-    MPCX_TRY(prg_fill_words(ctx, seed12, 0, PRG_POP_T0 + pop12 + i0, n, 1, (i64 *)c12, nullptr));
+    const BiGeom G{n_total, i0, n};
     const u64 *f0 = (const u64 *)from_p0, *f1 = (const u64 *)from_p1;
     u64 *o0 = (u64 *)C0, *o1 = (u64 *)C1;
-    return ew_launch(ctx, n, [=] __device__(u64 i) {
-        const u64 a0 = (B0[i] == 1 ? f0[n + i] : f0[i]) ^ f1[i];                   // :963
-        const u64 a12 = (B1[i] == 1 ? f1[2 * n + i] : f1[n + i]) ^ f0[2 * n + i];  // :996
-        o0[i] = a0 + c12[i];  // A0j[0] + A12j[0]
-        o1[i] = c02[i] + a12; // A0j[1] + A12j[1]
+    MPCX_TRY(prg_map1(ctx, seed12, G.c(PRG_POP_T0 + pop12), n, [=] __device__(u64 i, u64 c12) {
+        const u64 a0 = (B0[i] == 1 ? f0[n + i] : f0[i]) ^ f1[i]; // :963
+        o0[i] = a0 + c12;                                        // A0j[0] + A12j[0]
+    }));
+    return prg_map1(ctx, seed20, G.c(PRG_POP_T0 + pop20), n, [=] __device__(u64 i, u64 c02) {
+        const u64 a12 = (B1[i] == 1 ? f1[2 * n + i] : f1[n + i]) ^ f0[2 * n + i]; // :996
+        o1[i] = c02 + a12;                                                         // A0j[1] + A12j[1]
     });
 }
 

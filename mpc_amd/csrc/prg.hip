@@ -10,26 +10,13 @@
 #include <vector>
 
 #include "mpcx_internal.h"
+#include "prg_map.h"
 
 namespace {
 
 struct HostState {
     u64 seed, lcg, hash;
 };
-__host__ __device__ inline u64 prv_step(u64 &seed, u64 &lcg, u64 &hash) {
-    seed *= lcg * 2 + 1;
-#if defined(__HIP_DEVICE_COMPILE__)
-    // keep the product in registers as one value: otherwise the compiler re-derives it inside `lcg += seed`
-    // with a second 64-bit multiply-add, which costs more than the plain 64-bit add it replaces
-    asm volatile("" : "+v"(seed));
-#endif
-    const u64 rs = seed >> 32 | seed << 32;
-    hash += rs + 0xAAAAAAAAAAAAAAAAull;
-    lcg += seed + 0x5555555555555555ull;
-    seed ^= hash;
-    return lcg ^ rs;
-}
-
 struct Table {
     std::vector<PrgCk> host; // host[e] = state before stream word PRG_CK*e
     PrgCk *dev = nullptr;
@@ -98,49 +85,6 @@ __global__ __launch_bounds__(256) void prg_fill_kernel(const PrgCk *__restrict__
     }
 }
 
-
-// out[i] = (X ? X[i] : 0) + A[tA_first + i] - B[tB_first + i] for two streams A, B (the mask pop(next) - pop(prev)
-// that the ABY3 share and product segments add, ABY3Engine.cpp:70-74, :190-197) without materialising either stream.
-// One lane owns PRG_CK consecutive outputs; for each stream it starts from the checkpoint below its first word and
-// discards the words in between (none when the stream offsets are multiples of PRG_CK, as the pop stream's origin is).
-__global__ __launch_bounds__(256) void prg_diff_kernel(const PrgCk *__restrict__ ckA, const PrgCk *__restrict__ ckB,
-                                                       u64 tA_first, u64 tB_first, u64 count,
-                                                       const u64 *__restrict__ X, u64 *__restrict__ out) {
-    __shared__ u64 tile[256 * 17];
-    const u32 tid = threadIdx.x;
-    const u64 blk_r0 = (u64)blockIdx.x * 256; // first run of PRG_CK outputs of this workgroup
-    const u64 run = blk_r0 + tid;
-    const bool active = run * PRG_CK < count;
-    u64 sa = 0, la = 0, ha = 0, sb = 0, lb = 0, hb = 0;
-    const u32 skipA = (u32)(tA_first % PRG_CK), skipB = (u32)(tB_first % PRG_CK); // the same for every lane
-    if (active) {
-        const PrgCk a = ckA[(tA_first + run * PRG_CK) / PRG_CK], b = ckB[(tB_first + run * PRG_CK) / PRG_CK];
-        sa = a.seed, la = a.lcg, ha = a.hash;
-        sb = b.seed, lb = b.lcg, hb = b.hash;
-    }
-    for (u32 i = 0; i < skipA; i++) prv_step(sa, la, ha);
-    for (u32 i = 0; i < skipB; i++) prv_step(sb, lb, hb);
-    for (u32 it = 0; it < PRG_CK / 16; it++) {
-#pragma unroll
-        for (u32 k = 0; k < 16; k++) {
-            const u64 wa = prv_step(sa, la, ha);
-            tile[tid * 17 + k] = wa - prv_step(sb, lb, hb);
-        }
-        __syncthreads();
-#pragma unroll 4
-        for (u32 j = 0; j < 16; j++) {
-            const u32 idx = j * 256 + tid;
-            const u32 row = idx >> 4, col = idx & 15;
-            const u64 rel = (blk_r0 + row) * PRG_CK + it * 16 + col;
-            if (rel < count) {
-                u64 v = tile[row * 17 + col];
-                if (X) v += X[rel];
-                out[rel] = v;
-            }
-        }
-        __syncthreads();
-    }
-}
 
 } // namespace
 
@@ -212,20 +156,17 @@ int prg_fill_words(mpcx_ctx *ctx, u64 seed, u64 lcg, u64 t_first, u64 count, u64
     return prg_launch(ctx, seed, lcg, t_first, t_first + stride * count, stride == 1 ? 0 : 1, (u64 *)out, (u8 *)bools);
 }
 
-// out[i] = (X ? X[i] : 0) + streamA[tA_first + i] - streamB[tB_first + i], i in [0, count)
+// out[i] = (X ? X[i] : 0) + streamA[tA_first + i] - streamB[tB_first + i], i in [0, count): the mask
+// pop(next) - pop(prev) that the ABY3 share and product segments add (ABY3Engine.cpp:70-74, :190-197), without
+// materialising either stream
 int prg_fill_diff(mpcx_ctx *ctx, u64 seedA, u64 tA_first, u64 seedB, u64 tB_first, u64 count, const i64 *X, i64 *out) {
     if (count == 0) return 0;
     MPCX_REQUIRE(out, "prg_fill_diff: out is NULL");
-    const PrgCk *ckA, *ckB;
-    MPCX_TRY(mpcx_prg_table(ctx, seedA, 0, tA_first + count, &ckA));
-    MPCX_TRY(mpcx_prg_table(ctx, seedB, 0, tB_first + count, &ckB));
-    const u64 grid = ceil_div(ceil_div(count, PRG_CK), 256);
-    MPCX_REQUIRE(grid < (1ull << 31), "prg fill: range too large for one launch");
-    ProfScope ps(ctx, PROF_PRG);
-    hipLaunchKernelGGL(prg_diff_kernel, dim3((u32)grid), dim3(256), 0, ctx->stream, ckA, ckB, tA_first, tB_first, count,
-                       (const u64 *)X, (u64 *)out);
-    MPCX_LAUNCH_CHECK();
-    return 0;
+    const u64 *x = (const u64 *)X;
+    u64 *o = (u64 *)out;
+    auto diff = [] __device__(u64 a, u64 b) { return a - b; };
+    if (x) return prg_map2(ctx, seedA, tA_first, seedB, tB_first, count, diff, [=] __device__(u64 i, u64 v) { o[i] = x[i] + v; });
+    return prg_map2(ctx, seedA, tA_first, seedB, tB_first, count, diff, [=] __device__(u64 i, u64 v) { o[i] = v; });
 }
 
 // out[i] = (uint16)int_buff[first + i] % 67 (zero_to_one: 0 -> 1), one byte per value
