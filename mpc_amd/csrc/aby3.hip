@@ -186,15 +186,10 @@ int mpcx_aby3_share_bools_local(mpcx_ctx *ctx, const int8_t *X, uint64_t n, uint
                                 uint64_t seed_prev, uint64_t pop_prev, int8_t *out) {
     if (n == 0) return 0;
     MPCX_REQUIRE(out, "mpcx_aby3_share_bools_local: out is NULL");
-    void *ws;
-    MPCX_TRY(mpcx_ws(ctx, 16 * n, &ws));
-    u64 *a = (u64 *)ws, *b = a + n;
-    MPCX_TRY(prg_fill_words(ctx, seed_next, 0, PRG_POP_T0 + pop_next, n, 1, (i64 *)a, nullptr));
-    MPCX_TRY(prg_fill_words(ctx, seed_prev, 0, PRG_POP_T0 + pop_prev, n, 1, (i64 *)b, nullptr));
-    return ew_launch(ctx, n, [=] __device__(u64 i) {
-        i8 r = (i8)((a[i] & 1) ^ (b[i] & 1));
-        out[i] = X ? (i8)(r ^ X[i]) : r;
-    });
+    auto bit = [] __device__(u64 a, u64 b) { return (a ^ b) & 1; };
+    const u64 tn = PRG_POP_T0 + pop_next, tp = PRG_POP_T0 + pop_prev;
+    if (X) return prg_map2(ctx, seed_next, tn, seed_prev, tp, n, bit, [=] __device__(u64 i, u64 r) { out[i] = (i8)((i8)r ^ X[i]); });
+    return prg_map2(ctx, seed_next, tn, seed_prev, tp, n, bit, [=] __device__(u64 i, u64 r) { out[i] = (i8)r; });
 }
 
 // Z0 = X0*(Y0+Y1) + X1*Y0 = [X0 | X1] * [Y0+Y1 ; Y0]  (ABY3Engine.cpp:189) as ONE K-concatenated ring
@@ -350,14 +345,10 @@ int mpcx_aby3_trunc_local(mpcx_ctx *ctx, int party, const int64_t *X0, const int
     MPCX_REQUIRE(Y0 && (party == 2 || X0) && (party != 1 || X1), "mpcx_aby3_trunc_local: NULL pointer");
     if (party == 0) return ew_launch(ctx, n, [=] __device__(u64 i) { Y0[i] = X0[i] >> number; });
     if (party == 2) return prg_fill_words(ctx, seed12, 0, PRG_POP_T0 + pop12, n, 1, Y0, nullptr);
-    void *ws;
-    MPCX_TRY(mpcx_ws(ctx, 8 * n, &ws));
-    u64 *w = (u64 *)ws;
-    MPCX_TRY(prg_fill_words(ctx, seed12, 0, PRG_POP_T0 + pop12, n, 1, (i64 *)w, nullptr));
-    return ew_launch(ctx, n, [=] __device__(u64 i) {
+    return prg_map1(ctx, seed12, PRG_POP_T0 + pop12, n, [=] __device__(u64 i, u64 w) {
         i64 t = (i64)((u64)X0[i] + (u64)X1[i]);
         t >>= number;
-        Y0[i] = (i64)((u64)t - w[i]);
+        Y0[i] = (i64)((u64)t - w);
     });
 }
 

@@ -8,6 +8,7 @@
 #include <cstdlib>
 
 #include "mpcx_internal.h"
+#include "prg_map.h"
 
 namespace {
 
@@ -248,14 +249,10 @@ int mpcx_snn_share_local(mpcx_ctx *ctx, int party, const int64_t *X, uint64_t n,
         MPCX_HIP(hipMemsetAsync(out, 0, 8 * n, ctx->stream));
         return 0;
     }
-    void *ws;
-    MPCX_TRY(mpcx_ws(ctx, 8 * n, &ws));
-    u64 *w = (u64 *)ws;
-    MPCX_TRY(prg_fill_words(ctx, seed01, 0, PRG_POP_T0 + pop01, n, 1, (i64 *)w, nullptr));
     u64 *o = (u64 *)out;
     const u64 *x = (const u64 *)X;
-    if (party == 0) return ew_launch(ctx, n, [=] __device__(u64 i) { o[i] = 0 - w[i]; });
-    return ew_launch(ctx, n, [=] __device__(u64 i) { o[i] = x[i] + w[i]; });
+    if (party == 0) return prg_map1(ctx, seed01, PRG_POP_T0 + pop01, n, [=] __device__(u64 i, u64 w) { o[i] = 0 - w; });
+    return prg_map1(ctx, seed01, PRG_POP_T0 + pop01, n, [=] __device__(u64 i, u64 w) { o[i] = x[i] + w; });
 }
 
 int mpcx_snn_add_L1(mpcx_ctx *ctx, const int64_t *a, const int64_t *b, int64_t *out, uint64_t n) {
