@@ -177,8 +177,14 @@ def cpu_baseline(n=1536):
     phase(mul)
     phase(rev)
     dt = time.perf_counter() - t0
+    cpu = "unknown"
+    try:
+        cpu = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
+    except (OSError, StopIteration):
+        pass
     return {"value": 3 * 6 * n ** 3 / dt / 1e9, "unit": "Gop/s", "cores": 3, "kind": "port",
-            "sample": f"ABY3 {n}x{n} share_matrix x2 + matrix_mul + reveal_matrix, 3 party threads, {dt:.2f} s wall"}
+            "sample": f"ABY3 {n}x{n} share_matrix x2 + matrix_mul + reveal_matrix, 3 party threads, {dt:.2f} s wall",
+            "host": {"cpu": cpu, "logical_cpus": os.cpu_count()}}
 
 
 def _timed(torch, fn, reps=1):
