@@ -95,3 +95,72 @@ int prg_map2(mpcx_ctx *ctx, u64 seedA, u64 tA, u64 seedB, u64 tB, u64 count, G g
     MPCX_LAUNCH_CHECK();
     return 0;
 }
+
+// ---- buffer form: int_buff[i] is stream word 2i and bool_buff[i] the low bit of word 2i + 1 of a generator
+// (utils/PRgenerator.cpp:27-32, extended to every i).  Element i of the call reads int_buff[first[s] + i] of up to three
+// sections s of ONE generator (and bool_buff[first[0] + i]); g folds them, in the producing lane, into a value V
+// (trivially copyable, a multiple of 8 bytes) and f(i, V) runs in memory order.  A lane owns PRG_CK / 2 consecutive
+// elements; every 8 elements the workgroup visits its 256 x 8 values with consecutive threads on consecutive elements.
+template <int NS, class V, class G, class F>
+__global__ __launch_bounds__(256) void prg_buff_map_kernel(const PrgCk *__restrict__ ck, u64 f0, u64 f1, u64 f2, u64 count,
+                                                           G g, F f) {
+    static_assert(sizeof(V) % 8 == 0 && NS >= 1 && NS <= 3, "value layout");
+    constexpr u32 VW = sizeof(V) / 8, EPL = PRG_CK / 2, CH = 8, PITCH = CH * VW + 1;
+    __shared__ u64 tile[256 * PITCH];
+    const u32 tid = threadIdx.x;
+    const u64 blk_r0 = (u64)blockIdx.x * 256;
+    const u64 run = blk_r0 + tid;
+    const bool active = run * EPL < count;
+    const u64 first[3] = {f0, f1, f2};
+    u64 sd[NS], lc[NS], hs[NS];
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+        sd[s] = lc[s] = hs[s] = 0;
+        const u64 t = 2 * (first[s] + run * EPL);
+        if (active) {
+            const PrgCk c = ck[t / PRG_CK];
+            sd[s] = c.seed, lc[s] = c.lcg, hs[s] = c.hash;
+        }
+        const u32 skip = (u32)((2 * first[s]) % PRG_CK); // the same for every lane
+        for (u32 i = 0; i < skip; i++) prv_step(sd[s], lc[s], hs[s]);
+    }
+    for (u32 it = 0; it < EPL / CH; it++) {
+#pragma unroll
+        for (u32 e = 0; e < CH; e++) {
+            u64 w[NS];
+            u32 b0 = 0;
+#pragma unroll
+            for (int s = 0; s < NS; s++) {
+                w[s] = prv_step(sd[s], lc[s], hs[s]);
+                const u64 odd = prv_step(sd[s], lc[s], hs[s]);
+                if (s == 0) b0 = (u32)(odd & 1);
+            }
+            *(V *)&tile[tid * PITCH + e * VW] = g(w, b0);
+        }
+        __syncthreads();
+#pragma unroll 2
+        for (u32 j = 0; j < CH; j++) {
+            const u32 idx = j * 256 + tid;
+            const u32 row = idx / CH, col = idx % CH;
+            const u64 i = (blk_r0 + row) * EPL + it * CH + col;
+            if (i < count) f(i, *(const V *)&tile[row * PITCH + col * VW]);
+        }
+        __syncthreads();
+    }
+}
+
+template <int NS, class V, class G, class F>
+int prg_buff_map(mpcx_ctx *ctx, u64 seed, const u64 (&first)[NS], u64 count, G g, F f) {
+    if (count == 0) return 0;
+    u64 top = 0;
+    for (int s = 0; s < NS; s++) top = first[s] > top ? first[s] : top;
+    const PrgCk *ck;
+    MPCX_TRY(mpcx_prg_table(ctx, seed, 0, 2 * (top + count) + PRG_CK, &ck));
+    const u64 grid = ceil_div(ceil_div(count, PRG_CK / 2), 256);
+    MPCX_REQUIRE(grid < (1ull << 31), "prg map: range too large for one launch");
+    ProfScope ps(ctx, PROF_PRG);
+    hipLaunchKernelGGL((prg_buff_map_kernel<NS, V, G, F>), dim3((u32)grid), dim3(256), 0, ctx->stream, ck, first[0],
+                       NS > 1 ? first[NS > 1 ? 1 : 0] : 0, NS > 2 ? first[NS > 2 ? 2 : 0] : 0, count, g, f);
+    MPCX_LAUNCH_CHECK();
+    return 0;
+}

@@ -408,42 +408,40 @@ int mpcx_snn_pc_helper(mpcx_ctx *ctx, const uint16_t *d0, const uint16_t *d1, ui
 }
 
 // ---- shareConvert
-static int sc_rand_words(mpcx_ctx *ctx, u64 seed01, u64 n_total, u64 i0, u64 n, u64 **w0, u64 **w1, i8 **eta2) {
-    void *ws;
-    MPCX_TRY(mpcx_ws(ctx, 17 * n + 64, &ws));
-    *w0 = (u64 *)ws;
-    *w1 = *w0 + n;
-    *eta2 = (i8 *)(*w1 + n);
-    MPCX_TRY(prg_fill_words(ctx, seed01, 0, 2 * i0, n, 2, (i64 *)*w0, *eta2));                // :700-701
-    MPCX_TRY(prg_fill_words(ctx, seed01, 0, 2 * (n_total + i0), n, 2, (i64 *)*w1, nullptr)); // :702
-    return 0;
-}
+// r0 = int_buff01[i0 + i], r1 = int_buff01[n_total + i0 + i], eta'' = bool_buff01[i0 + i] (:700-702): consumed while
+// they are regenerated
+struct ScPick { // what a party keeps of (r0, r1, eta'')
+    u64 rj;     // its own summand, after the r == 0 adjustment
+    u64 bits;   // bit 0: alpha = (r < r0) (:710), bit 1: eta''
+};
 int mpcx_snn_sc_party_open(mpcx_ctx *ctx, int party, const int64_t *A, uint64_t n_total, uint64_t i0, uint64_t n,
                            uint64_t seed01, int64_t *x_out) {
     if (n == 0) return 0;
     MPCX_REQUIRE(party == 0 || party == 1, "mpcx_snn_sc_party_open: party %d", party);
     MPCX_REQUIRE(A && x_out, "mpcx_snn_sc_party_open: NULL pointer");
     MPCX_REQUIRE(i0 + n <= n_total, "mpcx_snn_sc_party_open: range outside the vector");
-    u64 *w0, *w1;
-    i8 *e2;
-    MPCX_TRY(sc_rand_words(ctx, seed01, n_total, i0, n, &w0, &w1, &e2));
-    return ew_launch(ctx, n, [=] __device__(u64 i) {
-        const ScRand s = sc_rand(w0[i], w1[i]);
-        x_out[i] = (i64)((u64)A[i] + (party == 0 ? s.r0 : s.r1)); // :718
-    });
+    const u64 first[2] = {i0, n_total + i0};
+    return prg_buff_map<2, u64>(
+        ctx, seed01, first, n,
+        [=] __device__(const u64(&w)[2], u32) {
+            const ScRand s = sc_rand(w[0], w[1]);
+            return party == 0 ? s.r0 : s.r1;
+        },
+        [=] __device__(u64 i, u64 rj) { x_out[i] = (i64)((u64)A[i] + rj); }); // :718
 }
 int mpcx_snn_sc_party_pc_inputs(mpcx_ctx *ctx, uint64_t n_total, uint64_t i0, uint64_t n, uint64_t seed01,
                                 int8_t *eta2_out, int64_t *rm1_out) {
     if (n == 0) return 0;
     MPCX_REQUIRE(eta2_out && rm1_out, "mpcx_snn_sc_party_pc_inputs: NULL pointer");
     MPCX_REQUIRE(i0 + n <= n_total, "mpcx_snn_sc_party_pc_inputs: range outside the vector");
-    u64 *w0, *w1;
-    i8 *e2;
-    MPCX_TRY(sc_rand_words(ctx, seed01, n_total, i0, n, &w0, &w1, &e2));
-    return ew_launch(ctx, n, [=] __device__(u64 i) {
-        eta2_out[i] = e2[i];
-        rm1_out[i] = (i64)(sc_rand(w0[i], w1[i]).R - 1); // :738
-    });
+    const u64 first[2] = {i0, n_total + i0};
+    return prg_buff_map<2, ScPick>(
+        ctx, seed01, first, n,
+        [=] __device__(const u64(&w)[2], u32 eta2) { return ScPick{sc_rand(w[0], w[1]).R - 1, (u64)eta2}; }, // :738
+        [=] __device__(u64 i, ScPick v) {
+            eta2_out[i] = (i8)v.bits;
+            rm1_out[i] = (i64)v.rj;
+        });
 }
 int mpcx_snn_sc_party_finish(mpcx_ctx *ctx, int party, const int64_t *A, const int64_t *delta_j,
                              const int64_t *eta1_j, uint64_t n_total, uint64_t i0, uint64_t n, uint64_t seed01,
@@ -452,26 +450,27 @@ int mpcx_snn_sc_party_finish(mpcx_ctx *ctx, int party, const int64_t *A, const i
     MPCX_REQUIRE(party == 0 || party == 1, "mpcx_snn_sc_party_finish: party %d", party);
     MPCX_REQUIRE(A && delta_j && eta1_j && y_out, "mpcx_snn_sc_party_finish: NULL pointer");
     MPCX_REQUIRE(i0 + n <= n_total, "mpcx_snn_sc_party_finish: range outside the vector");
-    u64 *w0, *w1;
-    i8 *e2;
-    MPCX_TRY(sc_rand_words(ctx, seed01, n_total, i0, n, &w0, &w1, &e2));
     const u64 pid = (u64)party;
-    return ew_launch(ctx, n, [=] __device__(u64 i) {
-        const ScRand s = sc_rand(w0[i], w1[i]);
-        const u64 rj = party == 0 ? s.r0 : s.r1;
-        const u64 alpha = s.R < s.r0;              // :710
-        const u64 a = (u64)A[i], x = a + rj;       // :718
-        const u64 beta = x < rj;                   // :719
-        const u64 eta2 = (u64)(i64)e2[i];
-        u64 eta = add_L_1((u64)eta1_j[i], pid * eta2);           // :750
-        u64 t = add_L_1((u64)eta1_j[i], (u64)eta1_j[i]) * eta2;  // :751-752
-        eta = sub_L_1(eta, t);                                   // :753
-        const u64 tj = (1 - pid) * (L_1 - 1 - alpha);            // :758
-        u64 theta = add_L_1(beta, tj);                           // :759
-        theta = add_L_1(theta, eta);
-        theta = add_L_1(theta, (u64)delta_j[i]);
-        y_out[i] = (i64)sub_L_1(a, theta); // :765
-    });
+    const u64 first[2] = {i0, n_total + i0};
+    return prg_buff_map<2, ScPick>(
+        ctx, seed01, first, n,
+        [=] __device__(const u64(&w)[2], u32 eta2) {
+            const ScRand s = sc_rand(w[0], w[1]);
+            return ScPick{party == 0 ? s.r0 : s.r1, (u64)(s.R < s.r0) | (u64)eta2 << 1}; // :710
+        },
+        [=] __device__(u64 i, ScPick v) {
+            const u64 rj = v.rj, alpha = v.bits & 1, eta2 = v.bits >> 1;
+            const u64 a = (u64)A[i], x = a + rj;       // :718
+            const u64 beta = x < rj;                   // :719
+            u64 eta = add_L_1((u64)eta1_j[i], pid * eta2);           // :750
+            u64 t = add_L_1((u64)eta1_j[i], (u64)eta1_j[i]) * eta2;  // :751-752
+            eta = sub_L_1(eta, t);                                   // :753
+            const u64 tj = (1 - pid) * (L_1 - 1 - alpha);            // :758
+            u64 theta = add_L_1(beta, tj);                           // :759
+            theta = add_L_1(theta, eta);
+            theta = add_L_1(theta, (u64)delta_j[i]);
+            y_out[i] = (i64)sub_L_1(a, theta); // :765
+        });
 }
 int mpcx_snn_sc_helper_split(mpcx_ctx *ctx, const int64_t *x0, const int64_t *x1, uint64_t n_total, uint64_t i0,
                              uint64_t n, uint64_t seedS, uint16_t *xbits0, int64_t *delta0, uint16_t *xbits1,
@@ -483,20 +482,21 @@ int mpcx_snn_sc_helper_split(mpcx_ctx *ctx, const int64_t *x0, const int64_t *x1
     // the cache request comes first: it may grow (and so move) the workspace the other pointers live in
     const u8 *rnd;
     ctx->rand_tick++;
-    MPCX_TRY(prg_buff_mod67_cached(ctx, seedS, 0, 64 * i0, 64 * n, 0, 80 * n, 16 * n, &rnd)); // :838-839
+    MPCX_TRY(prg_buff_mod67_cached(ctx, seedS, 0, 64 * i0, 64 * n, 0, 72 * n, 8 * n, &rnd)); // :838-839
     void *ws;
-    MPCX_TRY(mpcx_ws(ctx, 16 * n, &ws));
-    u64 *x = (u64 *)ws, *d0w = x + n;
-    MPCX_TRY(prg_fill_words(ctx, seedS, 0, 2 * i0, n, 2, (i64 *)d0w, nullptr)); // :848
+    MPCX_TRY(mpcx_ws(ctx, 8 * n, &ws));
+    u64 *x = (u64 *)ws;
     const u64 *a = (const u64 *)x0, *b = (const u64 *)x1;
-    MPCX_TRY(ew_launch(ctx, n, [=] __device__(u64 i) {
-        const u64 xv = a[i] + b[i]; // :824
-        const u64 delta = xv < a[i]; // :825
-        x[i] = xv;
-        const u64 D0 = d0w[i] % L_1; // :849
-        delta0[i] = (i64)D0;
-        delta1[i] = (i64)sub_L_1(delta, D0); // :851
-    }));
+    const u64 first[1] = {i0};
+    MPCX_TRY((prg_buff_map<1, u64>(
+        ctx, seedS, first, n, [] __device__(const u64(&w)[1], u32) { return w[0] % L_1; }, // :848-849
+        [=] __device__(u64 i, u64 D0) {
+            const u64 xv = a[i] + b[i];  // :824
+            const u64 delta = xv < a[i]; // :825
+            x[i] = xv;
+            delta0[i] = (i64)D0;
+            delta1[i] = (i64)sub_L_1(delta, D0); // :851
+        })));
     hipLaunchKernelGGL(bit_share_kernel, dim3(grid_for(8 * n)), dim3(256), 0, ctx->stream, (const u64 *)x, (const u64 *)rnd,
                        n, (uint4 *)xbits0, (uint4 *)xbits1);
     MPCX_LAUNCH_CHECK();
@@ -507,15 +507,13 @@ int mpcx_snn_sc_helper_eta(mpcx_ctx *ctx, const int8_t *eta1_plain, uint64_t n_t
     if (n == 0) return 0;
     MPCX_REQUIRE(eta1_plain && eta0 && eta1, "mpcx_snn_sc_helper_eta: NULL pointer");
     MPCX_REQUIRE(i0 + n <= n_total, "mpcx_snn_sc_helper_eta: range outside the vector");
-    void *ws;
-    MPCX_TRY(mpcx_ws(ctx, 8 * n, &ws));
-    u64 *w = (u64 *)ws;
-    MPCX_TRY(prg_fill_words(ctx, seedS, 0, 2 * (n_total + i0), n, 2, (i64 *)w, nullptr)); // :868
-    return ew_launch(ctx, n, [=] __device__(u64 i) {
-        const u64 e0 = w[i] % L_1; // :869
-        eta0[i] = (i64)e0;
-        eta1[i] = (i64)sub_L_1((u64)(i64)eta1_plain[i], e0); // :871
-    });
+    const u64 first[1] = {n_total + i0};
+    return prg_buff_map<1, u64>(
+        ctx, seedS, first, n, [] __device__(const u64(&w)[1], u32) { return w[0] % L_1; }, // :868-869
+        [=] __device__(u64 i, u64 e0) {
+            eta0[i] = (i64)e0;
+            eta1[i] = (i64)sub_L_1((u64)(i64)eta1_plain[i], e0); // :871
+        });
 }
 
 // ---- msb_L_1
@@ -527,22 +525,25 @@ int mpcx_snn_msbl1_helper_deal(mpcx_ctx *ctx, uint64_t n_total, uint64_t i0, uin
     MPCX_REQUIRE(((uintptr_t)xbits0 & 15) == 0 && ((uintptr_t)xbits1 & 15) == 0, "mpcx_snn_msbl1_helper_deal: xbits must be 16-byte aligned");
     const u8 *rnd;
     ctx->rand_tick++;
-    MPCX_TRY(prg_buff_mod67_cached(ctx, seedS, 0, 3 * n_total + 64 * i0, 64 * n, 0, 96 * n, 32 * n, &rnd)); // :922-923
+    MPCX_TRY(prg_buff_mod67_cached(ctx, seedS, 0, 3 * n_total + 64 * i0, 64 * n, 0, 72 * n, 8 * n, &rnd)); // :922-923
     void *ws;
-    MPCX_TRY(mpcx_ws(ctx, 32 * n, &ws));
-    u64 *w0 = (u64 *)ws, *w1 = w0 + n, *w2 = w1 + n, *xv = w2 + n;
-    MPCX_TRY(prg_fill_words(ctx, seedS, 0, 2 * i0, n, 2, (i64 *)w0, nullptr));                  // :911
-    MPCX_TRY(prg_fill_words(ctx, seedS, 0, 2 * (n_total + i0), n, 2, (i64 *)w1, nullptr));     // :913
-    MPCX_TRY(prg_fill_words(ctx, seedS, 0, 2 * (2 * n_total + i0), n, 2, (i64 *)w2, nullptr)); // :917
-    MPCX_TRY(ew_launch(ctx, n, [=] __device__(u64 i) {
-        const u64 X0 = w0[i] % L_1, X1 = w1[i] % L_1; // :912,:914
-        const u64 X = add_L_1(X0, X1);                // :915
-        xv[i] = X;
-        x0[i] = (i64)X0;
-        x1[i] = (i64)X1;
-        xlsb0[i] = (i64)w2[i];
-        xlsb1[i] = (i64)((X & 1) - w2[i]); // :918
-    }));
+    MPCX_TRY(mpcx_ws(ctx, 8 * n, &ws));
+    u64 *xv = (u64 *)ws;
+    struct Deal {
+        u64 X0, X1, lsb0;
+    };
+    const u64 first[3] = {i0, n_total + i0, 2 * n_total + i0};
+    MPCX_TRY((prg_buff_map<3, Deal>(
+        ctx, seedS, first, n,
+        [] __device__(const u64(&w)[3], u32) { return Deal{w[0] % L_1, w[1] % L_1, w[2]}; }, // :911-914, :917
+        [=] __device__(u64 i, Deal d) {
+            const u64 X = add_L_1(d.X0, d.X1); // :915
+            xv[i] = X;
+            x0[i] = (i64)d.X0;
+            x1[i] = (i64)d.X1;
+            xlsb0[i] = (i64)d.lsb0;
+            xlsb1[i] = (i64)((X & 1) - d.lsb0); // :918
+        })));
     // :922-926: the random byte is party 1's share, party 0 gets bit + 67 - it
     hipLaunchKernelGGL(bit_share_kernel, dim3(grid_for(8 * n)), dim3(256), 0, ctx->stream, (const u64 *)xv, (const u64 *)rnd,
                        n, (uint4 *)xbits1, (uint4 *)xbits0);
@@ -554,14 +555,13 @@ int mpcx_snn_msbl1_helper_beta(mpcx_ctx *ctx, const int8_t *beta1_plain, uint64_
     if (n == 0) return 0;
     MPCX_REQUIRE(beta1_plain && b0 && b1, "mpcx_snn_msbl1_helper_beta: NULL pointer");
     MPCX_REQUIRE(i0 + n <= n_total, "mpcx_snn_msbl1_helper_beta: range outside the vector");
-    void *ws;
-    MPCX_TRY(mpcx_ws(ctx, 8 * n, &ws));
-    u64 *w = (u64 *)ws;
-    MPCX_TRY(prg_fill_words(ctx, seedS, 0, 2 * (4 * n_total + i0), n, 2, (i64 *)w, nullptr)); // :953
-    return ew_launch(ctx, n, [=] __device__(u64 i) {
-        b0[i] = (i64)w[i];
-        b1[i] = (i64)((u64)(i64)beta1_plain[i] - w[i]); // :954
-    });
+    const u64 first[1] = {4 * n_total + i0};
+    return prg_buff_map<1, u64>(
+        ctx, seedS, first, n, [] __device__(const u64(&w)[1], u32) { return w[0]; }, // :953
+        [=] __device__(u64 i, u64 w) {
+            b0[i] = (i64)w;
+            b1[i] = (i64)((u64)(i64)beta1_plain[i] - w); // :954
+        });
 }
 int mpcx_snn_msbl1_party_open(mpcx_ctx *ctx, const int64_t *A, const int64_t *xj, uint64_t n, int64_t *r_out) {
     MPCX_REQUIRE((A && xj && r_out) || n == 0, "mpcx_snn_msbl1_party_open: NULL pointer");

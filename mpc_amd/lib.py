@@ -22,6 +22,12 @@ def load_library():
         if not os.path.exists(LIB_PATH):
             raise MpcxError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                             "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        # A process that also uses PyTorch must bring torch's bundled HIP runtime up first: once this library (linked
+        # against the system ROCm) has initialised HIP, torch no longer finds the device.
+        import sys
+        torch = sys.modules.get("torch")
+        if torch is not None and torch.cuda.is_available():
+            torch.cuda.init()
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.mpcx_last_error.restype = ctypes.c_char_p
         _lib.mpcx_last_error.argtypes = [ctypes.c_void_p]

@@ -15,3 +15,16 @@ def pytest_configure(config):
 def orc():
     from backends import OracleBackend
     return OracleBackend()
+
+
+@pytest.fixture(scope="session", autouse=True)
+def torch_runtime_first(request):
+    """GPU runs: bring PyTorch's HIP runtime up before libmpcx.so is loaded.  Some tests drive the library through
+    torch tensors; when the library (linked against the system ROCm) has initialised HIP first, torch's own bundled
+    runtime no longer finds the device ("No HIP GPUs are available")."""
+    marks = request.config.getoption("-m") or ""
+    if "gpu" in marks and "not gpu" not in marks:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    yield
