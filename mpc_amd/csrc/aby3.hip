@@ -1,7 +1,7 @@
 // Per-party local segments of ABY3Engine (mpc_engine/ABY3Engine.cpp) as HIP kernels.
 // All kernels are streaming, HBM-bound passes over 64-bit share words; the carry tree of msb() is
-// kept as packed words that halve in width every round, and only the wire messages are expanded to
-// one byte per bit.
+// kept as dense bit strings that halve every round, only the wire messages are expanded to one byte per
+// bit, and the pop-stream words a segment needs are consumed while they are regenerated (prg_map.h).
 #include "mpcx_internal.h"
 #include "prg_map.h"
 
