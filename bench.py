@@ -56,8 +56,9 @@ def prof_read(ctx, name):
 
 
 class Aby3MatmulJob:
-    def __init__(self, ctx, torch, dev, n, rank, world, host_gather=False, rows=None):
+    def __init__(self, ctx, torch, dev, n, rank, world, host_gather=False, rows=None, gather=None):
         self.ctx, self.torch, self.n, self.rank, self.world = ctx, torch, n, rank, world
+        self.gather = world > 1 if gather is None else gather  # the collective also runs in a 1-rank process group
         self.host_gather = host_gather
         self.rows, self.l, self.c = rows or n, n, n
         self.rows_total = self.rows * world
@@ -73,7 +74,7 @@ class Aby3MatmulJob:
         self.RX = [e(self.rows * self.l) for _ in range(3)]
         self.RY = [e(self.l * self.c) for _ in range(3)]
         self.Z0 = [e(self.rows * self.c) for _ in range(3)]
-        self.Zfull = [e(self.rows_total * self.c) for _ in range(3)] if world > 1 else None
+        self.Zfull = [e(self.rows_total * self.c) for _ in range(3)] if self.gather else None
         self.Zplain = [e(self.rows * self.c) for _ in range(3)]
         # pop-stream checkpoints for everything a step consumes (fresh engines every step)
         pops = self.plan["total"]
@@ -97,7 +98,7 @@ class Aby3MatmulJob:
             sn, sp = pair_seed(j, nx), pair_seed(j, pv)
             ctx.call("aby3_matmul_local_rows", self.RX[j], self.RX[nx], self.RY[j], self.RY[nx], self.rows, self.l,
                      self.c, self.row0, sn, pm, sp, pm, self.Z0[j])
-            if self.world > 1:
+            if self.gather:
                 # the message party j hands to the messenger is all row-blocks of its Z0: one all-gather per party,
                 # started as soon as the block exists so that it travels over xGMI while the next party's product runs
                 import torch.distributed as dist
@@ -356,7 +357,7 @@ def main():
     dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:  # under torch.distributed.run the collectives run even with one rank
         import torch.distributed as dist
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
@@ -373,7 +374,8 @@ def main():
     ctx = Context(dev_index)
     ctx.call("set_stream", torch.cuda.current_stream().cuda_stream)
 
-    job = Aby3MatmulJob(ctx, torch, dev, args.size, rank, world, host_gather=args.dist_backend == "gloo", rows=args.rows or None)
+    job = Aby3MatmulJob(ctx, torch, dev, args.size, rank, world, host_gather=args.dist_backend == "gloo", rows=args.rows or None,
+                        gather=dist is not None)
 
     def barrier():
         if dist is not None:
