@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void split_limbs_kernel(const u64 *__restrict_
     __syncthreads();
     // thread -> (row oo, 16 consecutive k): a wave takes 32 rows x both 16-byte halves of one 32-byte K block, so
     // each of its stores covers 1 KiB of contiguous plane memory
-    const u32 oo = (tid >> 1) & 31 | (tid >> 7) << 5, kc = (tid & 1) | ((tid >> 6) & 1) << 1;
+    const u32 oo = ((tid >> 1) & 31) | ((tid >> 7) << 5), kc = (tid & 1) | ((tid >> 6) & 1) << 1;
     u64 y[16];
 #pragma unroll
     for (u32 q = 0; q < 16; q++)
