@@ -21,7 +21,10 @@ struct Table {
     std::vector<PrgCk> host; // host[e] = state before stream word PRG_CK*e
     PrgCk *dev = nullptr;
     u64 dev_cap = 0, dev_count = 0;
-    std::vector<PrgCk *> retired; // older device copies a kernel in flight may still read
+    // Older, smaller device copies.  A table is shared by every context of the device, so a kernel of another
+    // thread may still read (or be about to be launched on) a copy when the table grows: copies are kept until the
+    // process ends.  Growth is geometric, so together they hold less than the live copy.
+    std::vector<PrgCk *> retired;
 };
 struct Key {
     int device;

@@ -190,6 +190,9 @@ def test_bad_shapes_are_rejected(gpu):
         gpu.ring_gemm(one, one, 0, 1, 1)
     with pytest.raises(MpcxError):
         gpu._go("aby3_msb_round_pre", np.zeros(4, np.uint64), 1, 3, ("out", np.int8, 8))
+    b = np.zeros(4, dtype=np.int8)
+    with pytest.raises(MpcxError, match="outside a vector"):  # elements [8, 12) of a 10-element vector
+        gpu.aby3_bit_inject_p2_pre(b, b, KEY20, 0, KEY12, 0, rng=(10, 8))
 
 
 @pytest.mark.parametrize("n", [1, 3, 13, 777])
