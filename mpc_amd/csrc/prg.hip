@@ -106,7 +106,10 @@ int mpcx_prg_table(mpcx_ctx *ctx, u64 seed, u64 lcg, u64 t_end, const PrgCk **de
         u64 ahead = need / 8;
         ahead = ahead < 4096 ? 4096 : ahead > 65536 ? 65536 : ahead;
         const u64 want = need + ahead;
-        T.host.reserve(want);
+        if (want > T.host.capacity()) { // grow the host copy geometrically too (reserve alone would allocate exactly)
+            const u64 geo = T.host.capacity() + T.host.capacity() / 2;
+            T.host.reserve(want > geo ? want : geo);
+        }
         PrgCk c = T.host.back();
         while (T.host.size() < want) {
             for (u64 i = 0; i < PRG_CK; i++) prv_step(c.seed, c.lcg, c.hash);
@@ -117,8 +120,9 @@ int mpcx_prg_table(mpcx_ctx *ctx, u64 seed, u64 lcg, u64 t_end, const PrgCk **de
         MPCX_HIP(hipSetDevice(ctx->device));
         const u64 have = T.host.size();
         if (T.dev_cap < have) {
-            u64 room = have / 2; // spare room for later growth without another reallocation
-            room = room < 4096 ? 4096 : room > (1u << 20) ? (1u << 20) : room;
+            // the first copy is sized to the request; a table that grows again is a pop stream on the move and gets
+            // half as much spare room again, so that the superseded copies stay a geometric series
+            const u64 room = (T.dev && have / 2 > 4096) ? have / 2 : 4096;
             const u64 cap = have + room;
             PrgCk *nd = nullptr;
             MPCX_HIP(hipMalloc((void **)&nd, cap * sizeof(PrgCk)));
