@@ -76,6 +76,7 @@ class Aby3MatmulJob:
         self.Z0 = [e(self.rows * self.c) for _ in range(3)]
         self.Zfull = [e(self.rows_total * self.c) for _ in range(3)] if self.gather else None
         self.Zplain = [e(self.rows * self.c) for _ in range(3)]
+        self.pending = [None, None, None]  # all-gathers in flight, per party
         # pop-stream checkpoints for everything a step consumes (fresh engines every step)
         pops = self.plan["total"]
         for k in (KEY01, KEY12, KEY20):
@@ -92,27 +93,36 @@ class Aby3MatmulJob:
             off = self.row0 * self.l
             ctx.call("aby3_share_local", self.X if j == 0 else None, self.rows * self.l, sn, off, sp, off, self.RX[j])
             ctx.call("aby3_share_local", self.Y if j == 0 else None, n2y, sn, n2x, sp, n2x, self.RY[j])
-        works = []
         for j in range(3):
             nx, pv = (j + 1) % 3, (j + 2) % 3
             sn, sp = pair_seed(j, nx), pair_seed(j, pv)
+            if self.pending[j] is not None:  # the previous step's message of this party still reads Z0[j]
+                self.pending[j].wait()
+                self.pending[j] = None
             ctx.call("aby3_matmul_local_rows", self.RX[j], self.RX[nx], self.RY[j], self.RY[nx], self.rows, self.l,
                      self.c, self.row0, sn, pm, sp, pm, self.Z0[j])
             if self.gather:
                 # the message party j hands to the messenger is all row-blocks of its Z0: one all-gather per party,
-                # started as soon as the block exists so that it travels over xGMI while the next party's product runs
+                # started as soon as the block exists.  It travels over xGMI while the following products run -- of
+                # this step and, for the last party, of the next one (the steps are independent jobs); it is waited
+                # for before its source block is overwritten, and drain() completes the last ones.
                 import torch.distributed as dist
                 if self.host_gather:  # rehearsal without RCCL (gloo): through host memory
                     parts = [self.torch.empty(self.Z0[j].numel(), dtype=self.torch.int64) for _ in range(self.world)]
                     dist.all_gather(parts, self.Z0[j].cpu())
                     self.Zfull[j].copy_(self.torch.cat(parts))
                 else:
-                    works.append(dist.all_gather_into_tensor(self.Zfull[j], self.Z0[j], async_op=True))
+                    self.pending[j] = dist.all_gather_into_tensor(self.Zfull[j], self.Z0[j], async_op=True)
         for j in range(3):
             ctx.call("aby3_reveal3", self.Z0[(j + 2) % 3], self.Z0[j], self.Z0[(j + 1) % 3], self.Zplain[j],
                      self.rows * self.c)
-        for w in works:  # the step is over when every message is complete
-            w.wait()
+
+    def drain(self):
+        """Completes the messages still in flight (inside the timed region: a job is done when its messages are)."""
+        for j in range(3):
+            if self.pending[j] is not None:
+                self.pending[j].wait()
+                self.pending[j] = None
 
     def ring_ops_per_step(self):
         return 3 * 3 * 2 * self.rows_total * self.l * self.c
@@ -127,6 +137,10 @@ class Aby3MatmulJob:
         """All parties reveal the same Z, and sampled entries equal the exact big-integer dot products."""
         t = self.torch
         assert t.equal(self.Zplain[0], self.Zplain[1]) and t.equal(self.Zplain[1], self.Zplain[2])
+        if self.gather:  # this rank's block of every gathered message is its own Z0
+            lo = self.row0 * self.c
+            for j in range(3):
+                assert t.equal(self.Zfull[j][lo:lo + self.rows * self.c], self.Z0[j]), "gathered message differs"
         X = self.X.view(self.rows, self.l).cpu().numpy().view(np.uint64)
         Y = self.Y.view(self.l, self.c).cpu().numpy().view(np.uint64)
         Z = self.Zplain[0].view(self.rows, self.c).cpu().numpy().view(np.uint64)
@@ -384,11 +398,13 @@ def main():
 
     for _ in range(args.warmup):
         job.step()
+    job.drain()
     barrier()
     ctx.call("profile", 1)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         job.step()
+    job.drain()
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
