@@ -116,3 +116,24 @@ def test_aby3_relu_chain_2_24(env):
     assert torch.equal(relu, torch.clamp(x, min=0))
     for j in range(3):  # replicated sharing: party j's second share is party j+1's first
         assert torch.equal(up(C[j][1]), up(C[(j + 1) % 3][0]))
+
+
+def test_aby3_relu_chain_2_28_in_batches(env):
+    """The 2^28-element ReLU chain as sixteen element ranges of 2^24 (n_total, i0, n): every range reveals max(x, 0)
+    although its pop-stream offsets are those of the whole vector (up to 7 * 2^28 words into each stream)."""
+    ctx, torch, dev, be = env
+    nt, n = 1 << 28, 1 << 24
+    x = torch.empty(n, dtype=torch.int64, device=dev)
+    up = lambda d: torch.from_numpy(be.down(d)).to(dev)
+    for b in (0, 7, 15):  # first, middle and last range (each is independent of the others)
+        i0 = b * n
+        ctx.call("prg_fill_pop", 21, 0, i0, n, x)
+        w = pr.World(be, record=False, n_total=nt, i0=i0)
+        Xs = pr.aby3_share(w, ctx.wrap(x, np.int64), n)
+        Gs, Ps = pr.aby3_add_prepare(w, Xs)
+        Zb = pr.aby3_msb(w, Gs, Ps)
+        C = pr.aby3_bit_inject(w, Xs, Zb)
+        relu = sum(up(be.ring_sub(Xs[j][0], C[j][0])) for j in range(3))
+        assert torch.equal(relu, torch.clamp(x, min=0)), f"range {b}"
+        for j in range(3):
+            assert torch.equal(up(C[j][1]), up(C[(j + 1) % 3][0])), f"range {b}: replicated shares disagree"
