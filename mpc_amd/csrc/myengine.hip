@@ -6,6 +6,7 @@
 // int_buff / bool_buff words and only the dealer's correction terms travel.  The buffers are regenerated on the
 // device for any index.  share / reveal / privateCompare's helper role are the SecureNN entry points.
 #include "mpcx_internal.h"
+#include "prg_map.h"
 
 namespace {
 
@@ -41,6 +42,11 @@ struct Tmp {
     }
     Tmp(const Tmp &) = delete;
     Tmp &operator=(const Tmp &) = delete;
+};
+
+// two values a producing lane hands over per element (prg_buff_map)
+struct MyPair {
+    u64 a, b;
 };
 
 // int_buff[first .. first+count) of a stream (and bool_buff into `bools` when given)
@@ -123,15 +129,13 @@ int mpcx_my_beaver_party_open_vecmul(mpcx_ctx *ctx, const int64_t *X, const int6
     if (n == 0) return 0;
     MPCX_REQUIRE(X && Y && ef_out, "mpcx_my_beaver_party_open_vecmul: NULL pointer");
     MPCX_REQUIRE(i0 + n <= n_total, "mpcx_my_beaver_party_open_vecmul: range outside the vector");
-    Tmp t(ctx);
-    MPCX_TRY(t.get(16 * n));
-    u64 *A = (u64 *)t.p, *B = A + n;
-    MPCX_TRY(buff(ctx, seed2, i0, n, A)); // :258-259
-    MPCX_TRY(buff(ctx, seed2, n_total + i0, n, B));
-    return ew_launch(ctx, n, [=] __device__(u64 k) {
-        ef_out[k] = (i64)((u64)X[k] - A[k]); // :262-263
-        ef_out[n + k] = (i64)((u64)Y[k] - B[k]);
-    });
+    const u64 first[2] = {i0, n_total + i0}; // A, B (:258-259), consumed while they are regenerated
+    return prg_buff_map<2, MyPair>(
+        ctx, seed2, first, n, [] __device__(const u64(&w)[2], u32) { return MyPair{w[0], w[1]}; },
+        [=] __device__(u64 k, MyPair ab) {
+            ef_out[k] = (i64)((u64)X[k] - ab.a); // :262-263
+            ef_out[n + k] = (i64)((u64)Y[k] - ab.b);
+        });
 }
 int mpcx_my_beaver_party_finish_vecmul(mpcx_ctx *ctx, int party, uint64_t seed2, const int64_t *C, const int64_t *ef_own,
                                        const int64_t *ef_peer, uint64_t n_total, uint64_t i0, uint64_t n, int64_t *Z) {
@@ -139,16 +143,14 @@ int mpcx_my_beaver_party_finish_vecmul(mpcx_ctx *ctx, int party, uint64_t seed2,
     MPCX_REQUIRE(party == 0 || party == 1, "mpcx_my_beaver_party_finish_vecmul: party %d", party);
     MPCX_REQUIRE(C && ef_own && ef_peer && Z, "mpcx_my_beaver_party_finish_vecmul: NULL pointer");
     MPCX_REQUIRE(i0 + n <= n_total, "mpcx_my_beaver_party_finish_vecmul: range outside the vector");
-    Tmp t(ctx);
-    MPCX_TRY(t.get(16 * n));
-    u64 *A = (u64 *)t.p, *B = A + n;
-    MPCX_TRY(buff(ctx, seed2, i0, n, A));
-    MPCX_TRY(buff(ctx, seed2, n_total + i0, n, B));
     const u64 pid = (u64)party;
-    return ew_launch(ctx, n, [=] __device__(u64 k) {
-        const u64 E = (u64)ef_peer[k] + (u64)ef_own[k], F = (u64)ef_peer[n + k] + (u64)ef_own[n + k]; // :276-277
-        Z[k] = (i64)((u64)C[k] + E * B[k] + A[k] * F + E * F * pid);                                  // :278
-    });
+    const u64 first[2] = {i0, n_total + i0};
+    return prg_buff_map<2, MyPair>(
+        ctx, seed2, first, n, [] __device__(const u64(&w)[2], u32) { return MyPair{w[0], w[1]}; },
+        [=] __device__(u64 k, MyPair ab) {
+            const u64 E = (u64)ef_peer[k] + (u64)ef_own[k], F = (u64)ef_peer[n + k] + (u64)ef_own[n + k]; // :276-277
+            Z[k] = (i64)((u64)C[k] + E * ab.b + ab.a * F + E * F * pid);                                  // :278
+        });
 }
 
 // ---- msb (:442-597), three rounds, boolean (XOR) output shares
@@ -178,21 +180,25 @@ int mpcx_my_msb_helper_beta(mpcx_ctx *ctx, const int8_t *beta1_plain, uint64_t n
     if (n == 0) return 0;
     MPCX_REQUIRE(beta1_plain && b0 && b1, "mpcx_my_msb_helper_beta: NULL pointer");
     MPCX_REQUIRE(i0 + n <= n_total, "mpcx_my_msb_helper_beta: range outside the vector");
-    MPCX_TRY(prg_fill_words(ctx, seedS, 0, 2 * (n_total + i0), n, 2, nullptr, b0)); // :519
-    return ew_launch(ctx, n, [=] __device__(u64 k) { b1[k] = (i8)(beta1_plain[k] ^ b0[k]); }); // :520
+    const u64 first[1] = {n_total + i0};
+    return prg_buff_map<1, u64>(
+        ctx, seedS, first, n, [] __device__(const u64(&)[1], u32 b) { return (u64)b; }, // :519
+        [=] __device__(u64 k, u64 b) {
+            b0[k] = (i8)b;
+            b1[k] = (i8)(beta1_plain[k] ^ (i8)b); // :520
+        });
 }
 int mpcx_my_msb_party_open(mpcx_ctx *ctx, const int64_t *A, uint64_t seed2, uint64_t i0, uint64_t n, int64_t *r_out) {
     if (n == 0) return 0;
     MPCX_REQUIRE(A && r_out, "mpcx_my_msb_party_open: NULL pointer");
-    Tmp t(ctx);
-    MPCX_TRY(t.get(8 * n));
-    u64 *w = (u64 *)t.p;
-    MPCX_TRY(buff(ctx, seed2, i0, n, w)); // :541
-    return ew_launch(ctx, n, [=] __device__(u64 k) {
-        const u64 d = 2 * (u64)A[k];   // :446
-        const u64 y = add_L_1(d, d);   // :451
-        r_out[k] = (i64)add_L_1(w[k] % L_1, y); // :548
-    });
+    const u64 first[1] = {i0};
+    return prg_buff_map<1, u64>(
+        ctx, seed2, first, n, [] __device__(const u64(&w)[1], u32) { return w[0] % L_1; }, // :541
+        [=] __device__(u64 k, u64 x) {
+            const u64 d = 2 * (u64)A[k];   // :446
+            const u64 y = add_L_1(d, d);   // :451
+            r_out[k] = (i64)add_L_1(x, y); // :548
+        });
 }
 int mpcx_my_msb_party_pc_inputs(mpcx_ctx *ctx, const int64_t *r_own, const int64_t *r_peer, uint64_t i0, uint64_t n,
                                 uint64_t seed01, int8_t *beta_out, int64_t *R_out) {
@@ -240,15 +246,13 @@ int mpcx_my_bit_inject_party_pre(mpcx_ctx *ctx, const int64_t *X, const int8_t *
                                  int64_t *y_out, int8_t *c_out) {
     if (n == 0) return 0;
     MPCX_REQUIRE(X && A && y_out && c_out, "mpcx_my_bit_inject_party_pre: NULL pointer");
-    Tmp t(ctx);
-    MPCX_TRY(t.get(9 * n + 64));
-    u64 *U = (u64 *)t.p;
-    i8 *B = (i8 *)(U + n);
-    MPCX_TRY(buff(ctx, seed2, i0, n, U, B)); // :610-611
-    return ew_launch(ctx, n, [=] __device__(u64 i) {
-        y_out[i] = (i64)((u64)X[i] - U[i]); // :619
-        c_out[i] = (i8)(B[i] ^ A[i]);       // :617
-    });
+    const u64 first[1] = {i0}; // U = int_buff[i0 + i], B = bool_buff[i0 + i] (:610-611)
+    return prg_buff_map<1, MyPair>(
+        ctx, seed2, first, n, [] __device__(const u64(&w)[1], u32 b) { return MyPair{w[0], (u64)b}; },
+        [=] __device__(u64 i, MyPair ub) {
+            y_out[i] = (i64)((u64)X[i] - ub.a);   // :619
+            c_out[i] = (i8)((i8)ub.b ^ A[i]);     // :617
+        });
 }
 int mpcx_my_bit_inject_party_post(mpcx_ctx *ctx, int party, uint64_t seed2, uint64_t i0, uint64_t n, const int64_t *y_own,
                                   const int8_t *c_own, const int64_t *y_peer, const int8_t *c_peer, const int64_t *V,
@@ -256,20 +260,18 @@ int mpcx_my_bit_inject_party_post(mpcx_ctx *ctx, int party, uint64_t seed2, uint
     if (n == 0) return 0;
     MPCX_REQUIRE(party == 0 || party == 1, "mpcx_my_bit_inject_party_post: party %d", party);
     MPCX_REQUIRE(y_own && c_own && y_peer && c_peer && V && W && S && T && Z, "mpcx_my_bit_inject_party_post: NULL pointer");
-    Tmp t(ctx);
-    MPCX_TRY(t.get(n + 64));
-    i8 *B = (i8 *)t.p;
-    MPCX_TRY(prg_fill_words(ctx, seed2, 0, 2 * i0, n, 2, nullptr, B)); // :611
     const u64 pid = (u64)party;
-    return ew_launch(ctx, n, [=] __device__(u64 i) {
-        const u64 y = (u64)y_peer[i] + (u64)y_own[i]; // :634
-        const i8 cp = (i8)(c_peer[i] ^ c_own[i]);     // :635
-        const u64 bj = (u64)(i64)B[i];
-        if (cp == 0)
-            Z[i] = (i64)((u64)V[i] + y * (bj - 2 * (u64)S[i])); // :654
-        else
-            Z[i] = (i64)((u64)W[i] + y * ((pid ^ bj) - 2 * (u64)T[i])); // :658
-    });
+    const u64 first[1] = {i0}; // B = bool_buff[i0 + i] (:611)
+    return prg_buff_map<1, u64>(
+        ctx, seed2, first, n, [] __device__(const u64(&)[1], u32 b) { return (u64)b; },
+        [=] __device__(u64 i, u64 bj) {
+            const u64 y = (u64)y_peer[i] + (u64)y_own[i]; // :634
+            const i8 cp = (i8)(c_peer[i] ^ c_own[i]);     // :635
+            if (cp == 0)
+                Z[i] = (i64)((u64)V[i] + y * (bj - 2 * (u64)S[i])); // :654
+            else
+                Z[i] = (i64)((u64)W[i] + y * ((pid ^ bj) - 2 * (u64)T[i])); // :658
+        });
 }
 
 // reveal_vec_bools (:777-807): XOR of two byte-per-boolean shares
