@@ -18,6 +18,7 @@ struct HostState {
     u64 seed, lcg, hash;
 };
 struct Table {
+    std::mutex mu; // walk and upload of THIS stream; streams are extended independently of one another
     std::vector<PrgCk> host; // host[e] = state before stream word PRG_CK*e
     PrgCk *dev = nullptr;
     u64 dev_cap = 0, dev_count = 0;
@@ -35,8 +36,12 @@ struct Key {
         return lcg < o.lcg;
     }
 };
-std::mutex g_mu;
+std::mutex g_mu; // guards the map itself (its nodes never move)
 std::map<Key, Table> g_tables;
+Table &table_of(int device, u64 seed, u64 lcg) {
+    std::lock_guard<std::mutex> g(g_mu);
+    return g_tables[Key{device, seed, lcg}];
+}
 
 // mode 0: every stream word -> out64[rel]                                  (pop stream)
 // mode 1: even words -> out64[rel/2], odd words' low bit -> out8[rel/2]     (int_buff / bool_buff)
@@ -92,8 +97,8 @@ __global__ __launch_bounds__(256) void prg_fill_kernel(const PrgCk *__restrict__
 } // namespace
 
 int mpcx_prg_table(mpcx_ctx *ctx, u64 seed, u64 lcg, u64 t_end, const PrgCk **dev) {
-    std::lock_guard<std::mutex> g(g_mu);
-    Table &T = g_tables[Key{ctx->device, seed, lcg}];
+    Table &T = table_of(ctx->device, seed, lcg);
+    std::lock_guard<std::mutex> g(T.mu);
     if (T.host.empty()) {
         u64 s = seed, l = lcg, h = 0;
         for (int i = 0; i < 5; i++) prv_step(s, l, h); // utils/PRgenerator.cpp:23-26
@@ -272,8 +277,9 @@ int mpcx_prg_state_at_pop(mpcx_ctx *ctx, uint64_t seed, uint64_t lcg, uint64_t p
     MPCX_TRY(mpcx_prg_table(ctx, seed, lcg, t, &ck));
     PrgCk c;
     {
-        std::lock_guard<std::mutex> g(g_mu);
-        c = g_tables[Key{ctx->device, seed, lcg}].host[t / PRG_CK];
+        Table &T = table_of(ctx->device, seed, lcg);
+        std::lock_guard<std::mutex> g(T.mu);
+        c = T.host[t / PRG_CK];
     }
     for (u64 i = (t / PRG_CK) * PRG_CK; i < t; i++) prv_step(c.seed, c.lcg, c.hash);
     state_out[0] = c.seed;
