@@ -94,6 +94,42 @@ __global__ __launch_bounds__(256) void prg_fill_kernel(const PrgCk *__restrict__
 }
 
 
+
+// out[i] = (uint16)int_buff[first + i] % 67 (0 -> 1 when zero_to_one) for a run whose first stream word is a
+// checkpoint: a lane's PRG_CK stream words are PRG_CK / 2 consecutive output bytes, which it packs in registers and
+// stores itself -- no exchange through LDS, no work on the discarded odd words beyond the generator step.
+__global__ __launch_bounds__(256) void prg_mod67_kernel(const PrgCk *__restrict__ ck, u64 seg0, u64 count, int zero_to_one,
+                                                        u8 *__restrict__ out) {
+    constexpr u32 BPL = PRG_CK / 2; // bytes per lane
+    const u64 lane = (u64)blockIdx.x * 256 + threadIdx.x;
+    const u64 b0 = lane * BPL;
+    if (b0 >= count) return;
+    const PrgCk c = ck[seg0 + lane];
+    u64 seed = c.seed, lcg = c.lcg, hash = c.hash;
+    u32 w[BPL / 4];
+#pragma unroll
+    for (u32 q = 0; q < BPL / 4; q++) {
+        u32 acc = 0;
+#pragma unroll
+        for (u32 k = 0; k < 4; k++) {
+            const u32 x = (u32)prv_step(seed, lcg, hash) & 0xFFFFu;
+            (void)prv_step(seed, lcg, hash);
+            // x % 67 for x < 2^16: floor(x / 67) = (x * 62602) >> 22 exactly, in 24-bit multiplies
+            u32 m = x - (u32)__umul24((u32)__umul24(x, 62602u) >> 22, 67u);
+            if (zero_to_one && m == 0) m = 1;
+            acc |= m << (8 * k);
+        }
+        w[q] = acc;
+    }
+    u8 *dst = out + b0;
+    if (b0 + BPL <= count) {
+#pragma unroll
+        for (u32 q = 0; q < BPL / 16; q++) *(uint4 *)(dst + 16 * q) = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+    } else {
+        for (u64 i = b0; i < count; i++) out[i] = (u8)(w[(i - b0) >> 2] >> (8 * ((i - b0) & 3)));
+    }
+}
+
 } // namespace
 
 int mpcx_prg_table(mpcx_ctx *ctx, u64 seed, u64 lcg, u64 t_end, const PrgCk **dev) {
@@ -185,6 +221,17 @@ int prg_fill_diff(mpcx_ctx *ctx, u64 seedA, u64 tA_first, u64 seedB, u64 tB_firs
 int prg_fill_buff_mod67(mpcx_ctx *ctx, u64 seed, u64 lcg, u64 first, u64 count, int zero_to_one, u8 *out) {
     if (count == 0) return 0;
     MPCX_REQUIRE(out, "prg_fill_buff_mod67: out is NULL");
+    if ((2 * first) % PRG_CK == 0 && ((uintptr_t)out & 15) == 0) { // the run starts on a checkpoint: register-only path
+        const PrgCk *ck;
+        MPCX_TRY(mpcx_prg_table(ctx, seed, lcg, 2 * (first + count) + PRG_CK, &ck));
+        const u64 grid = ceil_div(ceil_div(count, PRG_CK / 2), 256);
+        MPCX_REQUIRE(grid < (1ull << 31), "prg fill: range too large for one launch");
+        ProfScope ps(ctx, PROF_PRG);
+        hipLaunchKernelGGL(prg_mod67_kernel, dim3((u32)grid), dim3(256), 0, ctx->stream, ck, 2 * first / PRG_CK, count,
+                           zero_to_one, out);
+        MPCX_LAUNCH_CHECK();
+        return 0;
+    }
     return prg_launch(ctx, seed, lcg, 2 * first, 2 * first + 2 * count - 1, zero_to_one ? 3 : 2, nullptr, out);
 }
 
