@@ -1,5 +1,5 @@
 /* mpcx -- C ABI of the MI355X (gfx950) implementation of the per-party local arithmetic of
- * victerying/mpc's ABY3Engine and SecurennEngine.
+ * victerying/mpc's ABY3Engine, SecurennEngine and MyEngine.
  *
  * The reference has no FFI: its boundary is the C++ engine classes
  * (mpc_engine/ABY3Engine.hpp:24-54, mpc_engine/SecurennEngine.hpp:20-50) whose methods all have the
@@ -61,8 +61,8 @@ int mpcx_profile_read(mpcx_ctx *ctx, const char *kernel, double *total_ms, uint6
 int mpcx_reserve_workspace(mpcx_ctx *ctx, uint64_t bytes);
 
 /* ---- PRgenerator (utils/PRgenerator.cpp:3-42) ---- */
-/* Walks the stream on the host once and keeps a checkpoint every 256 outputs on host and device, so
- * that kernels can regenerate any range in parallel.  n_pops / n_buff: how far the pop stream / the
+/* Walks the stream on the host once and keeps a checkpoint every 64 outputs (24 bytes each) on host and
+ * device, so that kernels can regenerate any range in parallel; the table is shared by the contexts of a device.  n_pops / n_buff: how far the pop stream / the
  * buffers will be read.  Called implicitly (and lazily) by everything below. */
 int mpcx_prg_ckpt_build(mpcx_ctx *ctx, uint64_t seed, uint64_t lcg, uint64_t n_pops, uint64_t n_buff);
 /* int_buff[first .. first+count) -> ints (nullable), bool_buff[...] -> bools (nullable)   (:27-32) */
