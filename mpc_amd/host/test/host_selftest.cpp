@@ -346,7 +346,31 @@ template <class F> static void run3(F party) {
     t2.join();
 }
 
+// containers: copy / move behaviour callers rely on (after `X = std::move(Z)` Eigen leaves the old X in Z), and the
+// wire codecs' round trip through the row-major order
+static void container_checks() {
+    MatrixXl a(3, 2), b(5, 4);
+    for (size_t i = 0; i < 3; i++)
+        for (size_t j = 0; j < 2; j++) a(i, j) = (int64_t)(10 * i + j);
+    MatrixXl a0 = a;
+    a = std::move(b);
+    CHECK(a.rows() == 5 && a.cols() == 4 && b.rows() == 3 && b.cols() == 2 && b == a0);
+    MatrixXl c(std::move(b));
+    CHECK(c == a0 && b.rows() == 0 && b.cols() == 0 && b.size() == 0);
+    string wire;
+    matrix2string(c, wire);
+    CHECK(wire.size() == 48 && ((const int64_t *)wire.data())[1] == c(0, 1) && ((const int64_t *)wire.data())[2] == c(1, 0));
+    MatrixXl d(3, 2);
+    string2matrix(wire, d);
+    CHECK(d == c);
+    VecI64 v(4), w(2);
+    for (size_t i = 0; i < 4; i++) v[i] = (int64_t)i;
+    w = std::move(v);
+    CHECK(w.size() == 4 && v.size() == 2 && w[3] == 3);
+}
+
 int main() {
+    container_checks();
     run3(aby3_kat_party);
     run3(aby3_party);
     run3(snn_party);
