@@ -9,7 +9,9 @@ device buffers handed over by pointer (the messenger round is not part of the ho
 
 --gpus N (launched by torch.distributed.run, one rank per GPU): weak scaling over matmul row-blocks --
 X has 4096*N rows, rank g owns rows [4096 g, 4096 (g+1)), Y is replicated, and the row-blocks of each
-party's Z0 (the message to the previous party) are gathered with one RCCL all-gather per party.
+party's Z0 (the message to the previous party) are gathered with one RCCL all-gather per party that stays
+in flight while the following products run and is completed before the timed region ends.  The
+privateCompare / msb / ReLU items run on per-rank element ranges (n_total, i0, n) and are merged over ranks.
 
 value = ring operations of the reference's formulation (3 products, 2 ops per multiply-add:
 3 parties x 3*2*r*l*c) per second, whole job.  Extra keys report the privateCompare / MSB element rates,
