@@ -137,3 +137,27 @@ def test_aby3_relu_chain_2_28_in_batches(env):
         assert torch.equal(relu, torch.clamp(x, min=0)), f"range {b}"
         for j in range(3):
             assert torch.equal(up(C[j][1]), up(C[(j + 1) % 3][0])), f"range {b}: replicated shares disagree"
+
+
+@pytest.mark.parametrize("lay", [0, 1])
+def test_ring_gemm_ragged_large(env, lay):
+    """A 3001 x 5003 . 5003 x 2005 ring product (no dimension a multiple of the tile sizes; two K chunks when the parts
+    are concatenated), in both layouts and accumulating onto a previous result: Z v = C v + A (B v) over Z_2^64."""
+    ctx, torch, dev, _ = env
+    r, l, c = 3001, 5003, 2005
+    rng = np.random.default_rng(77 + lay)
+    A = rng.integers(-2 ** 63, 2 ** 63, (r, l), dtype=np.int64)
+    B = rng.integers(-2 ** 63, 2 ** 63, (l, c), dtype=np.int64)
+    C = rng.integers(-2 ** 63, 2 ** 63, (r, c), dtype=np.int64)
+    flat = (lambda M: np.ascontiguousarray(M.T).ravel()) if lay else (lambda M: M.ravel())
+    dA, dB, dZ = (torch.from_numpy(flat(M).copy()).to(dev) for M in (A, B, C))
+    ctx.call("ring_gemm_u64", dA, dB, dZ, r, l, c, lay, lay, lay, 1)
+    torch.cuda.synchronize()
+    Z = dZ.cpu().numpy()
+    Z = Z.reshape(c, r).T if lay else Z.reshape(r, c)
+    with np.errstate(over="ignore"):
+        Au, Bu, Cu, Zu = (M.view(np.uint64) if M.flags.c_contiguous else np.ascontiguousarray(M).view(np.uint64)
+                          for M in (A, B, C, Z))
+        for _ in range(4):
+            v = rng.integers(0, 1 << 64, c, dtype=np.uint64) | np.uint64(1)
+            assert np.array_equal(Zu @ v, Cu @ v + Au @ (Bu @ v))
