@@ -121,13 +121,9 @@ __global__ __launch_bounds__(256) void prg_mod67_kernel(const PrgCk *__restrict_
         }
         w[q] = acc;
     }
-    u8 *dst = out + b0;
-    if (b0 + BPL <= count) {
+    u8 *dst = out + b0; // count is a multiple of BPL (checked by the launcher)
 #pragma unroll
-        for (u32 q = 0; q < BPL / 16; q++) *(uint4 *)(dst + 16 * q) = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
-    } else {
-        for (u64 i = b0; i < count; i++) out[i] = (u8)(w[(i - b0) >> 2] >> (8 * ((i - b0) & 3)));
-    }
+    for (u32 q = 0; q < BPL / 16; q++) *(uint4 *)(dst + 16 * q) = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
 }
 
 } // namespace
@@ -221,7 +217,8 @@ int prg_fill_diff(mpcx_ctx *ctx, u64 seedA, u64 tA_first, u64 seedB, u64 tB_firs
 int prg_fill_buff_mod67(mpcx_ctx *ctx, u64 seed, u64 lcg, u64 first, u64 count, int zero_to_one, u8 *out) {
     if (count == 0) return 0;
     MPCX_REQUIRE(out, "prg_fill_buff_mod67: out is NULL");
-    if ((2 * first) % PRG_CK == 0 && ((uintptr_t)out & 15) == 0) { // the run starts on a checkpoint: register-only path
+    if ((2 * first) % PRG_CK == 0 && count % (PRG_CK / 2) == 0 && ((uintptr_t)out & 15) == 0) {
+        // the run starts on a checkpoint and ends on one (every caller asks for 64 bytes per element): register-only path
         const PrgCk *ck;
         MPCX_TRY(mpcx_prg_table(ctx, seed, lcg, 2 * (first + count) + PRG_CK, &ck));
         const u64 grid = ceil_div(ceil_div(count, PRG_CK / 2), 256);
