@@ -242,8 +242,11 @@ def bitwise_rates(ctx, torch, dev, log2n=24, rank=0, world=1):
 
     # ---- privateCompare kernels
     t0 = time.perf_counter()
-    ctx.call("prg_ckpt_build", KEY01, 0, 0, 128 * nt)
-    ctx.call("prg_ckpt_build", KEYS, 0, 0, 67 * nt + 64)
+    # the two generators are walked on two host threads (each stream has its own lock)
+    walks = [threading.Thread(target=ctx.call, args=("prg_ckpt_build", KEY01, 0, 0, 128 * nt)),
+             threading.Thread(target=ctx.call, args=("prg_ckpt_build", KEYS, 0, 0, 67 * nt + 64))]
+    [t.start() for t in walks]
+    [t.join() for t in walks]
     out["ckpt_build_s"] = round(time.perf_counter() - t0, 2)
     xb = torch.randint(0, 67, (64 * n,), dtype=torch.int16, device=dev)
     beta = torch.randint(0, 2, (n,), dtype=torch.int8, device=dev)
