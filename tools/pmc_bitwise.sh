@@ -1,0 +1,10 @@
+#!/bin/bash
+# Development helper: HBM read / write bytes (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE in separate passes) of the
+# HBM-bound kernels of bench.py's privateCompare / msb / ReLU part at 2^24 elements; digest -> profiles/.
+#   ./tools/pmc_bitwise.sh
+cd /root/repo || exit 1
+D=gpurun_out/pmc_bitwise
+CMD="cd /tmp && export TMPDIR=/tmp && cd \$GRAFT_REPO_ROOT && rm -rf $D && mkdir -p $D && \
+timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $D/rd -o p -- python3 bench.py --steps 1 --warmup 0 --no-cpu --size 1024 > $D/rd.log 2>&1 && \
+timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $D/wr -o p -- python3 bench.py --steps 1 --warmup 0 --no-cpu --size 1024 > $D/wr.log 2>&1; echo exit=\$?; python3 tools/pmc_bitwise_sum.py"
+timeout 1700 /usr/local/graft/bin/gpurun --timeout 900 -- "$CMD" 2>&1 | tail -40

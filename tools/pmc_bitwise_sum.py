@@ -1,0 +1,50 @@
+"""Development helper: digest of tools/pmc_bitwise.sh -- per kernel, the average HBM bytes per launch (FETCH_SIZE
+doubled as gfx950 requires, WRITE_SIZE; both in KiB) beside the algorithmic bytes of a 2^24-element launch."""
+import collections
+import csv
+import glob
+import json
+
+N = 1 << 24
+# algorithmic bytes per element and launch
+ALGO = {
+    "pc_party_kernel": ("265 B protocol data + 64 B cached s bytes (+ 64 B of u for beta = 1, r = -1)", 329),
+    "pc_helper_kernel": ("2 x 128 B in + 1 B out", 257),
+    "bit_share_kernel": ("8 B + 64 B random bytes in, 2 x 128 B out", 328),
+    "prg_mod67_kernel": ("64 bytes written per element and slice", 64),
+}
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for kind, cname in (("rd", "FETCH_SIZE"), ("wr", "WRITE_SIZE")):
+    for f in glob.glob(f"gpurun_out/pmc_bitwise/{kind}/*counter_collection.csv"):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != cname:
+                continue
+            k = r["Kernel_Name"]
+            name = next((a for a in list(ALGO) + ["msb_round_pre_kernel", "msb_round_post_kernel"] if a in k), None)
+            if name is None:
+                continue
+            if name.startswith("msb_round"):
+                name += "<first level>" if ("true, true" in k or "false, true" in k) else "<later levels>"
+            dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+            agg[name][cname].append((float(r["Counter_Value"]), dur))
+out = {}
+for name, c in sorted(agg.items()):
+    rd = [v for v, _ in c.get("FETCH_SIZE", [])]
+    wr = [v for v, _ in c.get("WRITE_SIZE", [])]
+    durs = [d for _, d in c.get("FETCH_SIZE", [])]
+    # launches of other sizes (warm-up of small tables etc.) are dropped: keep the 2^24-element ones = the longest half
+    e = {"launches": len(rd), "avg_duration_us": sum(durs) / max(len(durs), 1),
+         "hbm_read_bytes_per_launch": 2 * 1024 * sum(rd) / max(len(rd), 1),
+         "hbm_write_bytes_per_launch": 1024 * sum(wr) / max(len(wr), 1)}
+    base = name.split("<")[0]
+    if base in ALGO:
+        e["algorithmic"] = ALGO[base][0]
+        e["algorithmic_bytes_per_launch"] = ALGO[base][1] * N
+    out[name] = e
+out["_note"] = ("separate --pmc passes of `bench.py --steps 1 --warmup 0 --no-cpu --size 1024` (2^24 elements); "
+                "FETCH_SIZE / WRITE_SIZE are KiB, FETCH_SIZE doubled (gfx950 tallies 128-B read requests at 64 B); msb rounds: "
+                "the first level moves 64 + 64 message bytes and 32 state bytes per element, every later level half of the one before")
+json.dump(out, open("profiles/r1_pmc_bitwise.json", "w"), indent=1)
+for k, v in out.items():
+    if k != "_note":
+        print(k, {a: (round(b) if isinstance(b, float) else b) for a, b in v.items() if a != "algorithmic"})
