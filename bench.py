@@ -347,6 +347,14 @@ def merge_bitwise(per_rank):
     out["pc_helper_GBps_per_gpu"] = 257.0 * out["pc_helper_elems_per_s"] / g / 1e9
     out["pc_helper_hbm_frac"] = out["pc_helper_GBps_per_gpu"] / HBM_PEAK_GBS
     out["ranks"] = g
+    # HBM bytes per launch from the committed rocprofv3 --pmc passes (taken at 2^24 elements on one GPU)
+    path = os.path.join(ROOT, "profiles", "r1_pmc_bitwise.json")
+    if g == 1 and out.get("n") == 1 << 24 and os.path.exists(path):
+        pmc = json.load(open(path))
+        for k in ("pc_party_kernel", "pc_helper_kernel"):
+            out[k.replace("_kernel", "") + "_traffic"] = {
+                "measured": pmc[k]["hbm_read_bytes_per_launch"] + pmc[k]["hbm_write_bytes_per_launch"],
+                "algorithmic": pmc[k]["algorithmic_bytes_per_launch"], "unit": "bytes per launch"}
     return out
 
 
