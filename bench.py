@@ -322,6 +322,38 @@ def bitwise_rates(ctx, torch, dev, log2n=24, rank=0, world=1):
     out["aby3_relu_segments_ms"] = {k: round(v, 3) for k, v in sorted(seg.items(), key=lambda kv: -kv[1])}
     got = sum(torch.from_numpy(be.down(R[j])).to(dev) for j in range(3))
     assert torch.equal(got, torch.clamp(x, min=0)), "ABY3 ReLU chain: revealed values differ from max(x, 0)"
+    del R, got
+
+    # ---- MyEngine ReLU chain (test/test_Myengine.cpp, benchmark/benchmark1.cpp:180-204): msb -> bit_inject -> subtract,
+    # parties 0 / 1 and the dealer on this GPU; the drivers take whole vectors, so it runs on one rank only
+    if world == 1:
+        import my_protocols as mp
+        from my_backends import GpuMy
+
+        class ResidentMy(ResidentBackend, GpuMy):
+            pass
+
+        bm = ResidentMy(ctx, torch, dev)
+        xm = torch.div(x, 2, rounding_mode="floor")  # msb's domain is [-2^62, 2^62) (test/test_Myengine.cpp: pop / 2)
+        xmD = ctx.wrap(xm, np.int64)
+
+        def my_relu():
+            w = pr.World(bm, record=False)
+            Xs = mp.my_share(w, xmD, n)
+            Ab = mp.my_msb(w, Xs)
+            C = mp.my_bit_inject(w, Xs, Ab)
+            return [bm.ring_sub(Xs[j], C[j]) for j in range(2)]
+
+        my_relu()
+        bm.events = []
+        dt, R = _timed(torch, my_relu)
+        seg = bm.segment_ms()
+        bm.events = None
+        rate("my_relu_elems_per_s", n, dt)
+        out["my_relu_ms"] = round(dt * 1e3, 3)
+        out["my_relu_segments_ms"] = {k: round(v, 3) for k, v in sorted(seg.items(), key=lambda kv: -kv[1])}
+        got = torch.from_numpy(bm.down(R[0])).to(dev) + torch.from_numpy(bm.down(R[1])).to(dev)
+        assert torch.equal(got, torch.clamp(xm, min=0)), "MyEngine ReLU chain: revealed values differ from max(x, 0)"
     ctx.call("set_rand_cache", 4 * GiB)
     out["_counts"] = counts
     return out
