@@ -27,41 +27,20 @@ constexpr u32 KPAD = 64;                  // K extent of each concatenated part 
 constexpr u32 STAGE_BYTES = 8 * (RM + RN) * RK; // 48 KiB: all 8 limbs of the A and B tiles of one step
 
 // ---------------------------------------------------------------- split
-// planes[i][kb][o][k%32] = digit_i( src(o,k) (+ src2(o,k)) ),  src(o,k) = src[o*so + k*sk], k offset by koff
-// grid: (Kpart/64, Op/64); everything outside [0,O) x [0,K) is written as 0.
-__global__ __launch_bounds__(256) void split_limbs_kernel(const u64 *__restrict__ src, const u64 *__restrict__ src2,
-                                                          u64 O, u64 K, u64 so, u64 sk, i8 *__restrict__ planes,
-                                                          u64 Op, u64 Kp, u64 koff) {
-    __shared__ u64 tile[64][65];
-    const u32 tid = threadIdx.x;
-    const u64 o0 = (u64)blockIdx.y * 64, k0 = (u64)blockIdx.x * 64;
-    const bool k_fast = (sk == 1);
-    // all 16 (or 32) loads of a lane are issued before the first is used: 32 KiB in flight per workgroup
-    u64 v[16];
-#pragma unroll
-    for (u32 j = 0; j < 16; j++) {
-        const u32 a = tid & 63, b = (tid >> 6) + 4 * j;
-        const u64 o = o0 + (k_fast ? b : a), k = k0 + (k_fast ? a : b);
-        const bool in = o < O && k < K;
-        v[j] = in ? src[o * so + k * sk] : 0;
-        if (src2 && in) v[j] += src2[o * so + k * sk];
-    }
-#pragma unroll
-    for (u32 j = 0; j < 16; j++) {
-        const u32 a = tid & 63, b = (tid >> 6) + 4 * j;
-        tile[k_fast ? b : a][k_fast ? a : b] = v[j];
-    }
-    __syncthreads();
-    // thread -> (row oo, 16 consecutive k): a wave takes 32 rows x both 16-byte halves of one 32-byte K block, so
-    // each of its stores covers 1 KiB of contiguous plane memory
-    const u32 oo = ((tid >> 1) & 31) | ((tid >> 7) << 5), kc = (tid & 1) | ((tid >> 6) & 1) << 1;
-    u64 y[16];
-#pragma unroll
-    for (u32 q = 0; q < 16; q++)
-        y[q] = (tile[oo][kc * 16 + q] + 0x8080808080808080ull) ^ 0x8080808080808080ull;
-    const u64 plane_stride = Op * Kp;
-    const u64 kg = koff + k0 + kc * 16;
-    i8 *dst = planes + ((kg >> 5) * Op + o0 + oo) * RK + (kg & 31);
+// planes[i][kb][o][k%32] = digit_i( src(o,k) (+ src2(o,k)) ),  src(o,k) = src[o*so + k*sk], k offset by koff;
+// everything outside [0,O) x [0,K) is written as 0.  One launch serves a table of sources that share K and Kp
+// (the operands of all concatenated parts): grid (Kpart/64, max Op/64, jobs).
+struct SplitJob {
+    const u64 *src, *src2; // src2 (nullable) is added element-wise
+    i8 *planes;
+    u64 O, so, sk, Op, koff;
+};
+struct SplitJobs {
+    SplitJob j[16];
+};
+
+// byte i of each of y[0..15] -> 16 consecutive bytes of limb plane i
+__device__ inline void store_limbs(const u64 (&y)[16], i8 *dst, u64 plane_stride) {
 #pragma unroll
     for (u32 i = 0; i < 8; i++) {
         u32 w[4];
@@ -72,6 +51,53 @@ __global__ __launch_bounds__(256) void split_limbs_kernel(const u64 *__restrict_
         }
         *(uint4 *)(dst + i * plane_stride) = make_uint4(w[0], w[1], w[2], w[3]);
     }
+}
+
+// KFAST: k is the source's fast axis (sk == 1).  A lane's 16 consecutive k are then contiguous in memory, so the
+// 64 x 64 tile is read with k along the lanes and turned through LDS.  Otherwise o is the fast axis: a lane reads
+// its own 16 words (one per k row; a wave load covers two runs of 32 consecutive o) and nothing is exchanged.
+template <bool KFAST>
+__global__ __launch_bounds__(256) void split_limbs_kernel(SplitJobs jobs, u64 K, u64 Kp) {
+    const SplitJob &J = jobs.j[blockIdx.z];
+    const u32 tid = threadIdx.x;
+    const u64 o0 = (u64)blockIdx.y * 64, k0 = (u64)blockIdx.x * 64;
+    if (o0 >= J.Op) return;
+    const u64 *__restrict__ src = J.src, *__restrict__ src2 = J.src2;
+    const u64 O = J.O, so = J.so, sk = J.sk;
+    // thread -> (row oo, 16 consecutive k): a wave takes 32 rows x both 16-byte halves of one 32-byte K block, so
+    // each of its stores covers 1 KiB of contiguous plane memory
+    const u32 oo = ((tid >> 1) & 31) | ((tid >> 7) << 5), kc = (tid & 1) | ((tid >> 6) & 1) << 1;
+    u64 y[16];
+    if constexpr (KFAST) {
+        __shared__ u64 tile[64][65];
+        // all 16 (or 32) loads of a lane are issued before the first is used: 32 KiB in flight per workgroup
+        u64 v[16];
+#pragma unroll
+        for (u32 j = 0; j < 16; j++) {
+            const u64 o = o0 + (tid >> 6) + 4 * j, k = k0 + (tid & 63);
+            const bool in = o < O && k < K;
+            v[j] = in ? src[o * so + k] : 0;
+            if (src2 && in) v[j] += src2[o * so + k];
+        }
+#pragma unroll
+        for (u32 j = 0; j < 16; j++) tile[(tid >> 6) + 4 * j][tid & 63] = v[j];
+        __syncthreads();
+#pragma unroll
+        for (u32 q = 0; q < 16; q++) y[q] = tile[oo][kc * 16 + q];
+    } else {
+        const u64 o = o0 + oo;
+#pragma unroll
+        for (u32 q = 0; q < 16; q++) {
+            const u64 k = k0 + kc * 16 + q;
+            const bool in = o < O && k < K;
+            y[q] = in ? src[o * so + k * sk] : 0;
+            if (src2 && in) y[q] += src2[o * so + k * sk];
+        }
+    }
+#pragma unroll
+    for (u32 q = 0; q < 16; q++) y[q] = (y[q] + 0x8080808080808080ull) ^ 0x8080808080808080ull;
+    const u64 kg = J.koff + k0 + kc * 16;
+    store_limbs(y, J.planes + ((kg >> 5) * J.Op + o0 + oo) * RK + (kg & 31), J.Op * Kp);
 }
 
 // ---------------------------------------------------------------- gemm
@@ -383,15 +409,32 @@ int ring_gemm_parts(mpcx_ctx *ctx, const GemmPart *parts, int nparts, u64 r, u64
     int first = 1;
     for (u64 kb = 0; kb < l; kb += lc) {
         const u64 klen = (l - kb < lc) ? l - kb : lc;
-        for (int p = 0; p < nparts; p++) {
+        {
             ProfScope ps(ctx, PROF_SPLIT);
-            const u64 *a = (const u64 *)parts[p].A + kb * skA;
-            const u64 *b = (const u64 *)parts[p].B + kb * skB;
-            const u64 *b2 = parts[p].Bplus ? (const u64 *)parts[p].Bplus + kb * skB : nullptr;
-            hipLaunchKernelGGL(split_limbs_kernel, dim3((u32)(lc / 64), (u32)(Mp / 64)), dim3(256), 0, ctx->stream, a,
-                               (const u64 *)nullptr, r, klen, soA, skA, Apl, Mp, Kp, (u64)p * lc);
-            hipLaunchKernelGGL(split_limbs_kernel, dim3((u32)(lc / 64), (u32)(Np / 64)), dim3(256), 0, ctx->stream, b,
-                               b2, c, klen, soB, skB, Bpl, Np, Kp, (u64)p * lc);
+            SplitJobs fast, slow; // by access pattern: k contiguous in the source, or o contiguous
+            u32 nfast = 0, nslow = 0;
+            u64 fast_op = 0, slow_op = 0;
+            for (int p = 0; p < nparts; p++) {
+                const SplitJob ja{(const u64 *)parts[p].A + kb * skA, nullptr, Apl, r, soA, skA, Mp, (u64)p * lc};
+                const SplitJob jb{(const u64 *)parts[p].B + kb * skB,
+                                  parts[p].Bplus ? (const u64 *)parts[p].Bplus + kb * skB : nullptr, Bpl, c, soB, skB, Np,
+                                  (u64)p * lc};
+                for (const SplitJob &j : {ja, jb}) {
+                    if (j.sk == 1) {
+                        fast.j[nfast++] = j;
+                        if (j.Op > fast_op) fast_op = j.Op;
+                    } else {
+                        slow.j[nslow++] = j;
+                        if (j.Op > slow_op) slow_op = j.Op;
+                    }
+                }
+            }
+            if (nfast)
+                hipLaunchKernelGGL(split_limbs_kernel<true>, dim3((u32)(lc / 64), (u32)(fast_op / 64), nfast), dim3(256), 0,
+                                   ctx->stream, fast, klen, Kp);
+            if (nslow)
+                hipLaunchKernelGGL(split_limbs_kernel<false>, dim3((u32)(lc / 64), (u32)(slow_op / 64), nslow), dim3(256), 0,
+                                   ctx->stream, slow, klen, Kp);
         }
         {
             ProfScope ps(ctx, PROF_GEMM);

@@ -22,8 +22,7 @@ def torch_runtime_first(request):
     """GPU runs: bring PyTorch's HIP runtime up before libmpcx.so is loaded.  Some tests drive the library through
     torch tensors; when the library (linked against the system ROCm) has initialised HIP first, torch's own bundled
     runtime no longer finds the device ("No HIP GPUs are available")."""
-    marks = request.config.getoption("-m") or ""
-    if "gpu" in marks and "not gpu" not in marks:
+    if any(item.get_closest_marker("gpu") for item in request.session.items):  # deselected items are not listed
         import torch
         if torch.cuda.is_available():
             torch.cuda.init()
