@@ -65,11 +65,11 @@ __global__ __launch_bounds__(256) void prg_fill_kernel(const PrgCk *__restrict__
     for (u32 it = 0; it < PRG_CK / 16; it++) {
 #pragma unroll
         for (u32 k = 0; k < 16; k++) tile[tid * 17 + k] = prv_step(seed, lcg, hash);
-        __syncthreads();
+        prg_wave_sync(); // the exchange stays inside the wavefront (prg_map.h)
 #pragma unroll 4
         for (u32 j = 0; j < 16; j++) {
-            const u32 idx = j * 256 + tid;
-            const u32 row = idx >> 4, col = idx & 15;
+            const u32 idx = j * 64 + (tid & 63);
+            const u32 row = (tid & ~63u) + (idx >> 4), col = idx & 15;
             const u64 t = (blk_seg0 + row) * PRG_CK + it * 16 + col;
             if (t >= t_first && t < t_end) {
                 const u64 v = tile[row * 17 + col];
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void prg_fill_kernel(const PrgCk *__restrict__
                 }
             }
         }
-        __syncthreads();
+        prg_wave_sync();
     }
 }
 

@@ -2,11 +2,20 @@
 // handed to a functor as they are produced instead of being written to memory and read back.
 //
 // Geometry (the same as the fill kernels): a lane replays PRG_CK consecutive stream words from one checkpoint, so a
-// 256-thread workgroup owns 256 * PRG_CK consecutive words.  Every 16 steps the lanes park their words in LDS and
-// the workgroup then visits those 256 x 16 words in memory order -- consecutive threads get consecutive words -- so
-// whatever the functor loads or stores at an index derived from the word's position is coalesced in 128-byte runs.
+// wavefront owns 64 * PRG_CK consecutive words.  Every 16 steps the lanes park their words in LDS and the wavefront
+// then visits those 64 x 16 words in memory order -- consecutive lanes get consecutive words -- so whatever the
+// functor loads or stores at an index derived from the word's position is coalesced in 128-byte runs.  The exchange
+// stays inside one wavefront (whose LDS operations complete in program order), so no workgroup barrier is needed and
+// the waves of a workgroup drift apart: some generate while others store.
 #pragma once
 #include "mpcx_internal.h"
+
+// orders the LDS traffic of one wavefront for the compiler; the hardware already runs it in program order
+__device__ inline void prg_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 __host__ __device__ inline u64 prv_step(u64 &seed, u64 &lcg, u64 &hash) {
     seed *= lcg * 2 + 1;
@@ -52,15 +61,15 @@ __global__ __launch_bounds__(256) void prg_map_kernel(const PrgCk *__restrict__ 
             const u64 wa = prv_step(sa, la, ha);
             tile[tid * 17 + k] = TWO ? g(wa, prv_step(sb, lb, hb)) : wa;
         }
-        __syncthreads();
+        prg_wave_sync();
 #pragma unroll 4
         for (u32 j = 0; j < 16; j++) {
-            const u32 idx = j * 256 + tid;
-            const u32 row = idx >> 4, col = idx & 15;
+            const u32 idx = j * 64 + (tid & 63);
+            const u32 row = (tid & ~63u) + (idx >> 4), col = idx & 15;
             const u64 rel = (blk_r0 + row) * PRG_CK + it * 16 + col;
             if (rel < count) f(rel, tile[row * 17 + col]);
         }
-        __syncthreads();
+        prg_wave_sync();
     }
 }
 
@@ -100,7 +109,7 @@ int prg_map2(mpcx_ctx *ctx, u64 seedA, u64 tA, u64 seedB, u64 tB, u64 count, G g
 // (utils/PRgenerator.cpp:27-32, extended to every i).  Element i of the call reads int_buff[first[s] + i] of up to three
 // sections s of ONE generator (and bool_buff[first[0] + i]); g folds them, in the producing lane, into a value V
 // (trivially copyable, a multiple of 8 bytes) and f(i, V) runs in memory order.  A lane owns PRG_CK / 2 consecutive
-// elements; every 8 elements the workgroup visits its 256 x 8 values with consecutive threads on consecutive elements.
+// elements; every 8 elements the wavefront visits its 64 x 8 values with consecutive lanes on consecutive elements.
 template <int NS, class V, class G, class F>
 __global__ __launch_bounds__(256) void prg_buff_map_kernel(const PrgCk *__restrict__ ck, u64 f0, u64 f1, u64 f2, u64 count,
                                                            G g, F f) {
@@ -137,15 +146,15 @@ __global__ __launch_bounds__(256) void prg_buff_map_kernel(const PrgCk *__restri
             }
             *(V *)&tile[tid * PITCH + e * VW] = g(w, b0);
         }
-        __syncthreads();
+        prg_wave_sync();
 #pragma unroll 2
         for (u32 j = 0; j < CH; j++) {
-            const u32 idx = j * 256 + tid;
-            const u32 row = idx / CH, col = idx % CH;
+            const u32 idx = j * 64 + (tid & 63);
+            const u32 row = (tid & ~63u) + idx / CH, col = idx % CH;
             const u64 i = (blk_r0 + row) * EPL + it * CH + col;
             if (i < count) f(i, *(const V *)&tile[row * PITCH + col * VW]);
         }
-        __syncthreads();
+        prg_wave_sync();
     }
 }
 
