@@ -37,7 +37,8 @@ __host__ __device__ inline u64 prv_step(u64 &seed, u64 &lcg, u64 &hash) {
 template <bool TWO, class G, class F>
 __global__ __launch_bounds__(256) void prg_map_kernel(const PrgCk *__restrict__ ckA, const PrgCk *__restrict__ ckB,
                                                       u64 tA, u64 tB, u64 count, G g, F f) {
-    __shared__ u64 tile[256 * 17];
+    constexpr u32 CH = 16; // steps between two visits (8: 64-byte runs, 32: half the waves per CU; both measured slower)
+    __shared__ u64 tile[256 * (CH + 1)];
     const u32 tid = threadIdx.x;
     const u64 blk_r0 = (u64)blockIdx.x * 256; // first run of PRG_CK words of this workgroup
     const u64 run = blk_r0 + tid;
@@ -55,19 +56,19 @@ __global__ __launch_bounds__(256) void prg_map_kernel(const PrgCk *__restrict__ 
     for (u32 i = 0; i < skipA; i++) prv_step(sa, la, ha);
     if (TWO)
         for (u32 i = 0; i < skipB; i++) prv_step(sb, lb, hb);
-    for (u32 it = 0; it < PRG_CK / 16; it++) {
+    for (u32 it = 0; it < PRG_CK / CH; it++) {
 #pragma unroll
-        for (u32 k = 0; k < 16; k++) {
+        for (u32 k = 0; k < CH; k++) {
             const u64 wa = prv_step(sa, la, ha);
-            tile[tid * 17 + k] = TWO ? g(wa, prv_step(sb, lb, hb)) : wa;
+            tile[tid * (CH + 1) + k] = TWO ? g(wa, prv_step(sb, lb, hb)) : wa;
         }
         prg_wave_sync();
 #pragma unroll 4
-        for (u32 j = 0; j < 16; j++) {
+        for (u32 j = 0; j < CH; j++) {
             const u32 idx = j * 64 + (tid & 63);
-            const u32 row = (tid & ~63u) + (idx >> 4), col = idx & 15;
-            const u64 rel = (blk_r0 + row) * PRG_CK + it * 16 + col;
-            if (rel < count) f(rel, tile[row * 17 + col]);
+            const u32 row = (tid & ~63u) + idx / CH, col = idx % CH;
+            const u64 rel = (blk_r0 + row) * PRG_CK + it * CH + col;
+            if (rel < count) f(rel, tile[row * (CH + 1) + col]);
         }
         prg_wave_sync();
     }
