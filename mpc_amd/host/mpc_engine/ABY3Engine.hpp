@@ -1,16 +1,22 @@
-// ABY3 engine with the reference's public surface (mpc_engine/ABY3Engine.hpp:24-54): same constructor,
-// public members and method signatures.  Every method keeps the reference's round structure and wire
-// format; the arithmetic between two messenger rounds runs on the GPU through the C ABI in
-// include/mpcx.h (one call per local segment).
+// ABY3 engine: three parties, replicated 2-out-of-3 sharing over Z_2^64 (party j holds shares j and j+1).
+//
+// Source-compatible with callers of the reference class (mpc_engine/ABY3Engine.hpp:24-54): constructor, public
+// data members and every method keep their names, argument types and out-parameter style, so the reference's
+// test and benchmark programs compile against this header unchanged.  Each method keeps the reference's
+// sequence of messenger rounds and its wire format; what happens between two rounds runs on the GPU through
+// the C ABI of include/mpcx.h, one call per local segment.
 #pragma once
-#include "../utils/VirtuleMessenger.hpp"
-#include "../utils/PRgenerator.hpp"
-#include "../eigen-3.4.0/Eigen/Dense"
-#include "../utils/util.hpp"
 #include <array>
 #include <bitset>
+#include <string>
 #include <vector>
 
+#include "../eigen-3.4.0/Eigen/Dense"
+#include "../utils/PRgenerator.hpp"
+#include "../utils/VirtuleMessenger.hpp"
+#include "../utils/util.hpp"
+
+// generator keys: one per pair of parties, and each party's own (ABY3Engine.cpp:34-53)
 #define KEY01 0xAB01
 #define KEY12 0xBC12
 #define KEY20 0xCA20
@@ -22,35 +28,49 @@ using std::array;
 using std::bitset;
 using std::string;
 using std::vector;
+
 struct mpcx_ctx;
+
 class ABY3Engine {
   public:
-    VirtuleMessenger *messenger;
-    size_t party_id;
-    vector<PRgenerator> prgs;
-    vector<string> message_send;
-    vector<string> message_recv;
+    // the two shares a party holds of a vector / matrix / bit vector
+    using VecPair = array<VecI64, 2>;
+    using MatPair = array<MatrixXl, 2>;
+    using BitPair = array<vecbool, 2>;
+
     ABY3Engine(VirtuleMessenger *_messenger, size_t _party_id);
-    void share(const VecI64 &X_plain, array<VecI64, 2> &Xj);
-    void share_matrix(const MatrixXl &X_plain, array<MatrixXl, 2> &Xj);
-    void share_bools(const vecbool &X_plain, array<vecbool, 2> &Xj);
-
-    void reveal(const array<VecI64, 2> &Xj, VecI64 &X_plain);
-    void reveal_matrix(const array<MatrixXl, 2> &Xj, MatrixXl &X_plain);
-    void reveal_bools(const array<vecbool, 2> &Xj, vecbool &X_plain);
-    void reveal_bits(const array<VecI64, 2> &Xj, VecI64 &X_plain);
-
-    void matrix_mul(const array<MatrixXl, 2> &Xj, const array<MatrixXl, 2> &Yj, array<MatrixXl, 2> &Zj);
-    void vector_mul(const array<VecI64, 2> &Xj, const array<VecI64, 2> &Yj, array<VecI64, 2> &Zj);
-    void vecbool_mul(const array<vecbool, 2> &Xj, const array<vecbool, 2> &Yj, array<vecbool, 2> &Zj);
-    void add_prepare(const array<VecI64, 2> &Xj, array<VecI64, 2> &Gj, array<VecI64, 2> &Pj);
-    void msb(const array<VecI64, 2> &Gj, const array<VecI64, 2> &Pj, array<vecbool, 2> &Zj);
-
-    void trunc(const array<VecI64, 2> &Xj, array<VecI64, 2> &Yj, size_t number);
-    void bit_inject(const array<VecI64, 2> &Aj, const array<vecbool, 2> &Bj, array<VecI64, 2> &Cj);
-
     ABY3Engine(const ABY3Engine &other) = delete;
     ~ABY3Engine();
 
-    mpcx_ctx *gpu; // the engine's GPU context (one per engine, like its PRgenerators)
+    // ---- state the reference exposes (its tests read prgs and party_id directly)
+    VirtuleMessenger *messenger; // borrowed
+    size_t party_id;
+    vector<PRgenerator> prgs;    // prgs[i]: the stream shared with party i; prgs[party_id]: this party's own
+    vector<string> message_send; // three slots each, reused from call to call
+    vector<string> message_recv;
+    mpcx_ctx *gpu;               // this engine's GPU context (an addition)
+
+    // ---- input: party 0 contributes the plain values, everyone ends up with its two shares (:63-127)
+    void share(const VecI64 &plain, VecPair &out);
+    void share_matrix(const MatrixXl &plain, MatPair &out);
+    void share_bools(const vecbool &plain, BitPair &out);
+
+    // ---- output: every party learns the plain values (:132-175, :277-289)
+    void reveal(const VecPair &in, VecI64 &plain);
+    void reveal_matrix(const MatPair &in, MatrixXl &plain);
+    void reveal_bools(const BitPair &in, vecbool &plain);
+    void reveal_bits(const VecPair &in, VecI64 &plain); // XOR-shared words
+
+    // ---- products, one round each (:177-272)
+    void matrix_mul(const MatPair &X, const MatPair &Y, MatPair &Z);
+    void vector_mul(const VecPair &X, const VecPair &Y, VecPair &Z);
+    void vecbool_mul(const BitPair &X, const BitPair &Y, BitPair &Z);
+
+    // ---- sign extraction: carry generate / propagate words, then the prefix circuit (:295-467)
+    void add_prepare(const VecPair &X, VecPair &G, VecPair &P);
+    void msb(const VecPair &G, const VecPair &P, BitPair &Z);
+
+    // ---- fixed-point rescale and arithmetic-times-bit (:469-1038)
+    void trunc(const VecPair &X, VecPair &Y, size_t number);
+    void bit_inject(const VecPair &A, const BitPair &B, VecPair &C);
 };

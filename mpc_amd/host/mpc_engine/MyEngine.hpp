@@ -1,16 +1,21 @@
-// MyEngine with the reference's public surface (mpc_engine/MyEngine.hpp:24-48): same constructor, public
-// members and method signatures.  Two-party additive shares on parties 0/1, party 2 deals the correlated
-// randomness out of the pairwise generators' buffers; every method keeps the reference's rounds and wire format,
-// the arithmetic between rounds runs on the GPU through the C ABI in include/mpcx.h.  Buffer words are
-// regenerated on the device for every index, so sizes beyond BUFF_NUM = 160000 words work.
+// MyEngine: parties 0 and 1 hold additive shares over Z_2^64; party 2 deals correlated randomness out of the
+// buffers of the pairwise generators and plays the third role of the comparison.
+//
+// Source-compatible with callers of the reference class (mpc_engine/MyEngine.hpp:24-48): constructor, public
+// data members and every method keep their names, argument types and out-parameter style.  Rounds and wire
+// format are the reference's; the arithmetic between rounds runs on the GPU through the C ABI of
+// include/mpcx.h.  Buffer words are regenerated on the device for every index, so sizes beyond
+// BUFF_NUM = 160000 words work.
 #pragma once
-#include "../utils/VirtuleMessenger.hpp"
-#include "../utils/PRgenerator.hpp"
-#include "../eigen-3.4.0/Eigen/Dense"
-#include "../utils/util.hpp"
 #include <array>
 #include <bitset>
+#include <string>
 #include <vector>
+
+#include "../eigen-3.4.0/Eigen/Dense"
+#include "../utils/PRgenerator.hpp"
+#include "../utils/VirtuleMessenger.hpp"
+#include "../utils/util.hpp"
 
 #define KEY01 0xAB01
 #define KEY12 0xBC12
@@ -23,30 +28,38 @@ using std::array;
 using std::bitset;
 using std::string;
 using std::vector;
+
 struct mpcx_ctx;
+
 class MyEngine {
   public:
-    VirtuleMessenger *messenger;
+    MyEngine(VirtuleMessenger *_messenger, size_t _party_id);
+    MyEngine(const MyEngine &other) = delete;
+    ~MyEngine();
+
+    // ---- state the reference exposes
+    VirtuleMessenger *messenger; // borrowed
     size_t party_id;
-    vector<PRgenerator> prgs;
+    vector<PRgenerator> prgs;    // prgs[i]: the stream shared with party i; prgs[party_id]: this party's own
     vector<string> message_send;
     vector<string> message_recv;
-    MyEngine(VirtuleMessenger *_messenger, size_t _party_id);
-    ~MyEngine();
-    MyEngine(const MyEngine &other) = delete;
-    void share(const VecI64 &X_plain, VecI64 &Xj);
-    void share_matrix(const MatrixXl &X_plain, MatrixXl &Xj);
-    void reveal(const VecI64 &Xj, VecI64 &X_plain);
-    void reveal_matrix(const MatrixXl &Xj, MatrixXl &X_plain);
-    void matrix_mul(const MatrixXl &Xj, const MatrixXl &Yj, MatrixXl &Zj);
-    void vector_mul(const VecI64 &Xj, const VecI64 &Yj, VecI64 &Zj);
-    void privateCompare(const vector<zpshare> &Xbits_j, const vecbool &beta1_plain, const VecI64 &r_palin,
-                        vecbool &beta2_plain);
-    void msb(const VecI64 &Aj, vecbool &Bj);
-    void bit_inject(const VecI64 &Xj, const vecbool &Aj, VecI64 &Zj);
-    void reveal_vec_bools(const vecbool &Xj, vecbool &X_plain);
-    void reveal_L_1(const VecI64 &Xj, VecI64 &X_plain);
-    void reveal_zp(const vector<zpshare> &Xbits_j, vector<zpshare> &Xbits_plain);
+    mpcx_ctx *gpu;               // this engine's GPU context (an addition)
 
-    mpcx_ctx *gpu; // the engine's GPU context
+    // ---- input / output (MyEngine.cpp:54-143, :777-end)
+    void share(const VecI64 &plain, VecI64 &mine);
+    void share_matrix(const MatrixXl &plain, MatrixXl &mine);
+    void reveal(const VecI64 &mine, VecI64 &plain);
+    void reveal_matrix(const MatrixXl &mine, MatrixXl &plain);
+    void reveal_vec_bools(const vecbool &mine, vecbool &plain);
+    void reveal_L_1(const VecI64 &mine, VecI64 &plain);
+    void reveal_zp(const vector<zpshare> &mine, vector<zpshare> &plain);
+
+    // ---- Beaver products; party 2 reads A and B out of the buffers of prgs[0] / prgs[1] (:145-285)
+    void matrix_mul(const MatrixXl &X, const MatrixXl &Y, MatrixXl &Z);
+    void vector_mul(const VecI64 &X, const VecI64 &Y, VecI64 &Z);
+
+    // ---- comparison, sign bit as XOR-shared bits, one-round arithmetic-times-bit (:287-772)
+    void privateCompare(const vector<zpshare> &xbits, const vecbool &beta, const VecI64 &r, vecbool &beta_prime);
+    void msb(const VecI64 &A, vecbool &B);
+    void bit_inject(const VecI64 &X, const vecbool &A, VecI64 &Z);
 };

@@ -5,18 +5,23 @@
 // byte streams concurrently (poll + non-blocking I/O), so payloads far larger than the kernel's socket
 // buffers (the 128 MiB - 2 GiB matrix messages) cannot deadlock.
 #pragma once
-#include "VirtuleMessenger.hpp"
 #include <stddef.h>
-#define PORT 8000
+
+#include "VirtuleMessenger.hpp"
+
+#define PORT 8000 // party i listens on PORT + i
 
 class SocketMessenger : public VirtuleMessenger {
   public:
-    size_t party_id;
-    int server_fd;
-    int recv_fd[3];
-    int send_fd[3];
-    SocketMessenger(size_t _party_id);
+    explicit SocketMessenger(size_t _party_id); // blocks until both peers are connected
     SocketMessenger(const SocketMessenger &others) = delete;
-    virtual void send_and_recv(const vector<string> &message_send, vector<string> &message_recv) override;
-    virtual ~SocketMessenger();
+    ~SocketMessenger() override;
+
+    void send_and_recv(const vector<string> &message_send, vector<string> &message_recv) override;
+
+    // the reference keeps these public
+    size_t party_id;
+    int server_fd;  // listening socket
+    int recv_fd[3]; // accepted connections, by peer
+    int send_fd[3]; // outgoing connections, by peer
 };
