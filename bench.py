@@ -158,7 +158,7 @@ class Aby3MatmulJob:
                 assert np.array_equal(Z @ v, X @ (Y @ v)), "Z v != X (Y v)"
 
 
-def cpu_baseline(n=1536):
+def cpu_baseline(n=2048):
     """The CPU oracle (a port of the reference algorithm) on the same workload at a bounded size: three
     party threads, each single-threaded, as the reference runs three single-threaded processes."""
     from backends import OracleBackend
