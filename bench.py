@@ -204,6 +204,59 @@ def cpu_baseline(n=2048):
             "host": {"cpu": cpu, "logical_cpus": os.cpu_count()}}
 
 
+def cpu_bitwise(log2n=18):
+    """The CPU oracle on the privateCompare / msb / ReLU items at a bounded size (they are O(n)): one thread plays
+    every role in turn, as bitwise_rates does on the GPU.  Inputs as there (privateCompare: r = -1 on every fifth
+    element; msb: pop / 2; ReLU: pops)."""
+    import protocols as pr
+    from backends import OracleBackend
+    orc = OracleBackend()
+    n = 1 << log2n
+    rng = np.random.default_rng(3)
+    out = {"n": n, "cores": 1, "kind": "port"}
+
+    def timed(fn):
+        t0 = time.perf_counter()
+        r = fn()
+        return time.perf_counter() - t0, r
+
+    xb = rng.integers(0, 67, 64 * n, dtype=np.uint16)
+    beta = rng.integers(0, 2, n, dtype=np.int8)
+    r = rng.integers(-2 ** 62, 2 ** 62, n, dtype=np.int64)
+    r[2::5] = -1
+    d0 = orc.snn_pc_party(0, xb, beta, r, n, 0, KEY01)  # first call: the generator buffers are extended to 128 n words
+    dt, d0 = timed(lambda: orc.snn_pc_party(0, xb, beta, r, n, 0, KEY01))
+    out["pc_party_elems_per_s"] = n / dt
+    d1 = orc.snn_pc_party(1, xb, beta, r, n, 0, KEY01)
+    dt, _ = timed(lambda: orc.snn_pc_helper(d0, d1))
+    out["pc_helper_elems_per_s"] = n / dt
+
+    a = orc.prg_fill_pop(22, 0, n) // 2
+
+    def snn_msb():
+        w = pr.World(orc, record=False)
+        return pr.snn_msb(w, pr.snn_share(w, a, n)[:2])
+
+    snn_msb()
+    dt, B = timed(snn_msb)
+    assert np.array_equal(B[0] + B[1], (a < 0).astype(np.int64))
+    out["snn_msb_elems_per_s"] = n / dt
+
+    x = orc.prg_fill_pop(21, 0, n)
+
+    def aby3_relu():
+        w = pr.World(orc, record=False)
+        Xs = pr.aby3_share(w, x, n)
+        Gs, Ps = pr.aby3_add_prepare(w, Xs)
+        C = pr.aby3_bit_inject(w, Xs, pr.aby3_msb(w, Gs, Ps))
+        return [orc.ring_sub(Xs[j][0], C[j][0]) for j in range(3)]
+
+    dt, R = timed(aby3_relu)
+    assert np.array_equal(R[0] + R[1] + R[2], np.maximum(x, 0))
+    out["aby3_relu_elems_per_s"] = n / dt
+    return out
+
+
 def _timed(torch, fn, reps=1):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -502,6 +555,8 @@ def main():
             res["bitwise"] = merge_bitwise(bitwise)
         if world == 1 and not args.no_cpu:
             res["cpu_baseline"] = cpu_baseline()
+            if "bitwise" in res and "error" not in res["bitwise"]:
+                res["bitwise"]["cpu_baseline"] = cpu_bitwise()
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()
