@@ -110,9 +110,14 @@ int prg_fill_diff(mpcx_ctx *ctx, u64 seedA, u64 tA_first, u64 seedB, u64 tB_firs
 // The same bytes through the context's cache: *out points at cached device memory.  Entries requested since
 // the caller last advanced ctx->rand_tick are never evicted, so a call bumps the tick once and may then hold
 // several slices.  A slice that does not fit the cache budget is generated at byte ws_offset of the context
-// workspace, which is grown to ws_total bytes (pass the same ws_total for every request of one call).
+// workspace, which is grown to ws_total bytes (pass the same ws_total for every request of one call) -- or, with
+// left_to_caller non-null, is NOT generated: *left_to_caller becomes 1 and the caller fills the part it needs.
 int prg_buff_mod67_cached(mpcx_ctx *ctx, u64 seed, u64 lcg, u64 first, u64 count, int zero_to_one, u64 ws_total,
-                          u64 ws_offset, const u8 **out);
+                          u64 ws_offset, const u8 **out, int *left_to_caller = nullptr);
+// out[64 e + k] = (uint16)int_buff[first + 64 e + k] % 67 for the *listed elements e of list only (both in device
+// memory, written by an earlier kernel on the stream)
+int prg_fill_buff_mod67_listed(mpcx_ctx *ctx, u64 seed, u64 lcg, u64 first, u64 n_elems, int zero_to_one, const u32 *list,
+                               const u32 *listed, u8 *out);
 void prg_rand_cache_clear(mpcx_ctx *ctx);
 // Z_67 sharing of the 64 bits of v[i]: first[i][k] = rnd[64 i + k] (one byte, already % 67),
 // second[i][k] = (bit_k(v[i]) + 67 - first[i][k]) % 67; first / second are 16-byte aligned

@@ -98,17 +98,11 @@ __global__ __launch_bounds__(256) void prg_fill_kernel(const PrgCk *__restrict__
 // out[i] = (uint16)int_buff[first + i] % 67 (0 -> 1 when zero_to_one) for a run whose first stream word is a
 // checkpoint: a lane's PRG_CK stream words are PRG_CK / 2 consecutive output bytes, which it packs in registers and
 // stores itself -- no exchange through LDS, no work on the discarded odd words beyond the generator step.
-__global__ __launch_bounds__(256) void prg_mod67_kernel(const PrgCk *__restrict__ ck, u64 seg0, u64 count, int zero_to_one,
-                                                        u8 *__restrict__ out) {
-    constexpr u32 BPL = PRG_CK / 2; // bytes per lane
-    const u64 lane = (u64)blockIdx.x * 256 + threadIdx.x;
-    const u64 b0 = lane * BPL;
-    if (b0 >= count) return;
-    const PrgCk c = ck[seg0 + lane];
+// PRG_CK / 2 bytes (uint16)int_buff % 67 from one checkpoint, packed four to a word
+__device__ inline void mod67_run(const PrgCk c, int zero_to_one, u32 (&w)[PRG_CK / 8]) {
     u64 seed = c.seed, lcg = c.lcg, hash = c.hash;
-    u32 w[BPL / 4];
 #pragma unroll
-    for (u32 q = 0; q < BPL / 4; q++) {
+    for (u32 q = 0; q < PRG_CK / 8; q++) {
         u32 acc = 0;
 #pragma unroll
         for (u32 k = 0; k < 4; k++) {
@@ -121,9 +115,37 @@ __global__ __launch_bounds__(256) void prg_mod67_kernel(const PrgCk *__restrict_
         }
         w[q] = acc;
     }
+}
+
+__global__ __launch_bounds__(256) void prg_mod67_kernel(const PrgCk *__restrict__ ck, u64 seg0, u64 count, int zero_to_one,
+                                                        u8 *__restrict__ out) {
+    constexpr u32 BPL = PRG_CK / 2; // bytes per lane
+    const u64 lane = (u64)blockIdx.x * 256 + threadIdx.x;
+    const u64 b0 = lane * BPL;
+    if (b0 >= count) return;
+    u32 w[BPL / 4];
+    mod67_run(ck[seg0 + lane], zero_to_one, w);
     u8 *dst = out + b0; // count is a multiple of BPL (checked by the launcher)
 #pragma unroll
     for (u32 q = 0; q < BPL / 16; q++) *(uint4 *)(dst + 16 * q) = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+}
+
+// The same bytes for the listed elements only: element e owns 64 bytes = two checkpoint runs, and lane t of the
+// launch fills half (t & 1) of element list[t >> 1], for t < 2 * *listed; the bytes of other elements stay untouched.
+__global__ __launch_bounds__(256) void prg_mod67_listed_kernel(const PrgCk *__restrict__ ck, u64 seg0,
+                                                               const u32 *__restrict__ list,
+                                                               const u32 *__restrict__ listed, int zero_to_one,
+                                                               u8 *__restrict__ out) {
+    static_assert(PRG_CK == 64, "an element's 64 bytes are two checkpoint runs");
+    const u64 total = 2 * (u64)*listed;
+    for (u64 t = (u64)blockIdx.x * 256 + threadIdx.x; t < total; t += (u64)gridDim.x * 256) {
+        const u64 run = 2 * (u64)list[t >> 1] + (t & 1);
+        u32 w[8];
+        mod67_run(ck[seg0 + run], zero_to_one, w);
+        u8 *dst = out + run * 32;
+        *(uint4 *)dst = make_uint4(w[0], w[1], w[2], w[3]);
+        *(uint4 *)(dst + 16) = make_uint4(w[4], w[5], w[6], w[7]);
+    }
 }
 
 } // namespace
@@ -232,6 +254,24 @@ int prg_fill_buff_mod67(mpcx_ctx *ctx, u64 seed, u64 lcg, u64 first, u64 count, 
     return prg_launch(ctx, seed, lcg, 2 * first, 2 * first + 2 * count - 1, zero_to_one ? 3 : 2, nullptr, out);
 }
 
+// out[64 e + k] = (uint16)int_buff[first + 64 e + k] % 67 (zero_to_one: 0 -> 1) for the *listed elements e of list
+// only (device memory, filled by an earlier kernel on the stream); first is a multiple of 32, out 16-byte aligned
+int prg_fill_buff_mod67_listed(mpcx_ctx *ctx, u64 seed, u64 lcg, u64 first, u64 n_elems, int zero_to_one, const u32 *list,
+                               const u32 *listed, u8 *out) {
+    if (n_elems == 0) return 0;
+    MPCX_REQUIRE(out && list && listed, "prg_fill_buff_mod67_listed: NULL pointer");
+    MPCX_REQUIRE((2 * first) % PRG_CK == 0 && ((uintptr_t)out & 15) == 0, "prg_fill_buff_mod67_listed: unaligned run");
+    const PrgCk *ck;
+    MPCX_TRY(mpcx_prg_table(ctx, seed, lcg, 2 * (first + 64 * n_elems) + PRG_CK, &ck));
+    u64 grid = ceil_div(2 * n_elems, 256);
+    if (grid > 2048) grid = 2048; // the lanes stride over the list, whose length only the device knows
+    ProfScope ps(ctx, PROF_PRG);
+    hipLaunchKernelGGL(prg_mod67_listed_kernel, dim3((u32)grid), dim3(256), 0, ctx->stream, ck, 2 * first / PRG_CK, list,
+                       listed, zero_to_one, out);
+    MPCX_LAUNCH_CHECK();
+    return 0;
+}
+
 void prg_rand_cache_clear(mpcx_ctx *ctx) {
     if (ctx->rand_cache.empty()) return;
     (void)hipSetDevice(ctx->device);
@@ -242,7 +282,8 @@ void prg_rand_cache_clear(mpcx_ctx *ctx) {
 }
 
 int prg_buff_mod67_cached(mpcx_ctx *ctx, u64 seed, u64 lcg, u64 first, u64 count, int zero_to_one, u64 ws_total,
-                          u64 ws_offset, const u8 **out) {
+                          u64 ws_offset, const u8 **out, int *left_to_caller) {
+    if (left_to_caller) *left_to_caller = 0;
     const int mode = zero_to_one ? 3 : 2;
     const u64 epoch = ctx->rand_tick; // entries touched in this epoch belong to the call in progress
     for (auto &e : ctx->rand_cache)
@@ -272,7 +313,10 @@ int prg_buff_mod67_cached(mpcx_ctx *ctx, u64 seed, u64 lcg, u64 first, u64 count
         void *ws;
         MPCX_TRY(mpcx_ws(ctx, ws_total, &ws));
         u8 *fallback = (u8 *)ws + ws_offset;
-        MPCX_TRY(prg_fill_buff_mod67(ctx, seed, lcg, first, count, zero_to_one, fallback));
+        if (left_to_caller)
+            *left_to_caller = 1;
+        else
+            MPCX_TRY(prg_fill_buff_mod67(ctx, seed, lcg, first, count, zero_to_one, fallback));
         *out = fallback;
         return 0;
     }

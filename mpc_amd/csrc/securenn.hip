@@ -163,6 +163,37 @@ __global__ __launch_bounds__(256) void pc_party_kernel(int party, int variant, c
     }
 }
 
+// the elements whose c comes from u (beta = 1 and r = -1; the same test as in pc_party_kernel), in any order.
+// A workgroup collects the hits of PC_LIST_CHUNK elements in LDS and reserves their places in the list with one
+// global atomic: one per wavefront would queue a quarter of a million additions on one address at 2^24 elements.
+constexpr u32 PC_LIST_CHUNK = 4096;
+__global__ __launch_bounds__(256) void pc_list_u_kernel(const i8 *__restrict__ beta, const i64 *__restrict__ r, u64 n,
+                                                        u32 *__restrict__ list, u32 *__restrict__ listed) {
+    __shared__ u32 hits[PC_LIST_CHUNK];
+    __shared__ u32 count, base;
+    const u32 tid = threadIdx.x, lane = tid & 63;
+    if (tid == 0) count = 0;
+    __syncthreads();
+    for (u32 it = 0; it < PC_LIST_CHUNK / 256; it++) {
+        const u64 i = (u64)blockIdx.x * PC_LIST_CHUNK + it * 256 + tid;
+        bool need = false;
+        if (i < n) {
+            const int bt = beta[i];
+            need = bt != 0 && !(bt == 1 && (u64)r[i] != ~0ull);
+        }
+        const u64 m = __ballot(need);
+        if (m == 0) continue; // the same for the whole wavefront
+        u32 at = 0;
+        if (lane == 0) at = atomicAdd(&count, (u32)__popcll(m));
+        at = __shfl(at, 0);
+        if (need) hits[at + __popcll(m & ((1ull << lane) - 1))] = (u32)i;
+    }
+    __syncthreads();
+    if (tid == 0 && count) base = atomicAdd(listed, count);
+    __syncthreads();
+    for (u32 k = tid; k < count; k += 256) list[base + k] = hits[k];
+}
+
 // privateCompare, party 2 (:655-669): beta'[i] = any_k((d0[i][k] + d1[i][k]) % 67 == 0)
 __global__ __launch_bounds__(256) void pc_helper_kernel(const uint4 *__restrict__ d0, const uint4 *__restrict__ d1, u64 n,
                                                         i8 *__restrict__ beta_out) {
@@ -371,10 +402,24 @@ int mpcx_snn_pc_party(mpcx_ctx *ctx, int party, const uint16_t *xbits, const int
     MPCX_REQUIRE(xbits && beta && r && d_out, "mpcx_snn_pc_party: NULL pointer");
     MPCX_REQUIRE(i0 + n <= n_total, "mpcx_snn_pc_party: range outside the vector");
     MPCX_REQUIRE(((uintptr_t)xbits & 15) == 0 && ((uintptr_t)d_out & 15) == 0, "mpcx_snn_pc_party: xbits/d_out must be 16-byte aligned");
+    MPCX_REQUIRE(n < (1ull << 32), "mpcx_snn_pc_party: too many elements for one call");
     const u8 *S, *U;
     ctx->rand_tick++;
-    MPCX_TRY(prg_buff_mod67_cached(ctx, seed01, 0, 64 * i0, 64 * n, 1, 128 * n, 0, &S));                     // :523,525-529
-    MPCX_TRY(prg_buff_mod67_cached(ctx, seed01, 0, 64 * n_total + 64 * i0, 64 * n, 1, 128 * n, 64 * n, &U)); // :524,530-534
+    // workspace when the bytes are not cached: s, u, then the list of the elements that read u and its length
+    const u64 ws_list = 128 * n, ws_total = ws_list + 4 * n + 16;
+    int u_left = 0;
+    MPCX_TRY(prg_buff_mod67_cached(ctx, seed01, 0, 64 * i0, 64 * n, 1, ws_total, 0, &S));                              // :523,525-529
+    MPCX_TRY(prg_buff_mod67_cached(ctx, seed01, 0, 64 * n_total + 64 * i0, 64 * n, 1, ws_total, 64 * n, &U, &u_left)); // :524,530-534
+    if (u_left) {
+        // Not cached: u is only read by the elements with beta = 1 and r = -1, so only their 64 bytes are made
+        // (a generator step costs as much as the comparison itself; the s bytes are needed by every element).
+        u32 *list = (u32 *)(U - 64 * n + ws_list), *listed = list + n;
+        MPCX_HIP(hipMemsetAsync(listed, 0, sizeof(u32), ctx->stream));
+        hipLaunchKernelGGL(pc_list_u_kernel, dim3((u32)ceil_div(n, PC_LIST_CHUNK)), dim3(256), 0, ctx->stream, beta, r, n, list,
+                           listed);
+        MPCX_LAUNCH_CHECK();
+        MPCX_TRY(prg_fill_buff_mod67_listed(ctx, seed01, 0, 64 * n_total + 64 * i0, n, 1, list, listed, (u8 *)U));
+    }
     ProfScope ps(ctx, PROF_PC_PARTY);
     hipLaunchKernelGGL(pc_party_kernel, dim3(grid_for(8 * n)), dim3(256), 0, ctx->stream, party, 0, (const uint4 *)xbits, beta,
                        r, (const u64 *)S, (const u64 *)U, n, (uint4 *)d_out);

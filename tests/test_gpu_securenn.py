@@ -85,6 +85,32 @@ def test_private_compare_arbitrary_uint16_and_beta(gpu, orc):
     assert np.array_equal(gpu.snn_pc_helper(xb, d1), orc.snn_pc_helper(xb, d1))
 
 
+@pytest.mark.parametrize("n", [1, 63, 4099, 70001])
+def test_private_compare_without_the_byte_cache(gpu, orc, n):
+    """With the cache of generator bytes switched off the u bytes are generated for the elements that read them
+    only (beta = 1 and r = -1, or a beta outside {0, 1}); the result is the oracle's, in element ranges too."""
+    rng = np.random.default_rng(n)
+    xb = rng.integers(0, 67, 64 * n, dtype=np.uint16)
+    beta = rng.integers(0, 2, n, dtype=np.int8)
+    beta[5::11] = 3
+    r = rnd(rng, n)
+    r[2::5] = -1
+    want = [orc.snn_pc_party(party, xb, beta, r, n, 0, KEY01) for party in (0, 1)]
+    gpu.ctx.call("set_rand_cache", 0)
+    try:
+        for party in (0, 1):
+            assert np.array_equal(gpu.snn_pc_party(party, xb, beta, r, n, 0, KEY01), want[party])
+        i0 = n // 3
+        m = n - i0
+        got = gpu.snn_pc_party(1, xb[64 * i0:], beta[i0:], r[i0:], n, i0, KEY01)
+        assert np.array_equal(got, want[1][64 * i0:])
+        none = np.zeros(n, dtype=np.int8)  # no element reads u: nothing is listed
+        assert np.array_equal(gpu.snn_pc_party(0, xb, none, r, n, 0, KEY01), orc.snn_pc_party(0, xb, none, r, n, 0, KEY01))
+        assert m > 0
+    finally:
+        gpu.ctx.call("set_rand_cache", 4 << 30)
+
+
 def test_snn_matmul_config_golden(gpu, orc):
     n = 64
     wd = prg_pops(20, 0, 2 * n * n)
