@@ -146,11 +146,13 @@ __global__ __launch_bounds__(256) void pc_party_kernel(int party, int variant, c
 #pragma unroll
             for (int j = 0; j < 8; j++) {
                 const u32 uk = ((j < 4 ? ub.x : ub.y) >> (8 * (j & 3))) & 0xFF;
+                // :577-578: (1 - party)(1 + u) + (67 - party) u stays below 2^16 for u < 67, so it is 1 + 68 u = 1 + u
+                // (party 0) or 66 u = -u (party 1) mod 67; the generated u bytes are in [1, 66].  Position 0 (:582): u, -u.
                 u32 ck;
-                if (q != 0 || j != 0) // :577-578: (1 - party)(1 + u) + (67 - party) u, below 2^16 for u < 67
-                    ck = mod67_u16(pid == 0 ? 1 + mul24(P + 1, uk) : mul24(P - 1, uk));
+                if (pid == 0)
+                    ck = (q != 0 || j != 0) ? (uk == P - 1 ? 0 : uk + 1) : uk;
                 else
-                    ck = pid == 0 ? uk : P - uk; // :582
+                    ck = P - uk;
                 const u32 sk = ((j < 4 ? sb.x : sb.y) >> (8 * (j & 3))) & 0xFF;
                 d2[j >> 1] |= mod67_u16(mul24(sk, ck)) << (16 * (j & 1));
             }
