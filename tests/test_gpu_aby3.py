@@ -77,6 +77,26 @@ def test_ring_gemm_accumulate_and_mixed_layouts(gpu, orc):
         assert np.array_equal(gpu.ring_gemm(A, B, r, l, c, la, lb, lc, C=C0), orc.ring_gemm(A, B, r, l, c, la, lb, lc, C=C0))
 
 
+def test_ring_gemm_random_shapes_and_layouts(gpu, orc):
+    """Forty random shapes (with every dimension equal to 1 among them) in every combination of operand and result
+    layouts, with and without accumulation, against numpy's wrapping uint64 product."""
+    rng = np.random.default_rng(2024)
+    shapes = [(1, 1, 7), (1, 9, 1), (6, 1, 1), (1, 70, 130), (130, 70, 1), (65, 1, 67)]
+    shapes += [tuple(int(v) for v in rng.integers(1, 300, 3)) for _ in range(34)]
+    for k, (r, l, c) in enumerate(shapes):
+        la, lb, lc, acc = k & 1, (k >> 1) & 1, (k >> 2) & 1, (k >> 3) & 1
+        A = rng.integers(0, 1 << 64, (r, l), dtype=np.uint64)
+        B = rng.integers(0, 1 << 64, (l, c), dtype=np.uint64)
+        C0 = rng.integers(0, 1 << 64, (r, c), dtype=np.uint64)
+        flat = lambda M, lay: (np.ascontiguousarray(M.T) if lay else np.ascontiguousarray(M)).ravel().view(np.int64)
+        with np.errstate(over="ignore"):
+            want = A @ B + (C0 if acc else np.uint64(0))
+        got = gpu.ring_gemm(flat(A, la), flat(B, lb), r, l, c, la, lb, lc, C=flat(C0, lc) if acc else None)
+        got = got.view(np.uint64)
+        got = got.reshape(c, r).T if lc else got.reshape(r, c)
+        assert np.array_equal(got, want), f"shape {(r, l, c)} layouts {(la, lb, lc)} accumulate {acc}"
+
+
 def test_relayout(gpu):
     a = np.arange(37 * 91, dtype=np.int64)
     assert np.array_equal(gpu.relayout(a, 37, 91, 0, 1), np.ascontiguousarray(a.reshape(37, 91).T).ravel())
