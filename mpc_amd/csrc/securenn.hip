@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void pc_party_kernel(int party, int variant, c
         u64 rv = 0;
         int bt = 0;
         if (live) {
-            const uint4 xv = xbits[c];
+            const uint4 xv = ld_stream(xbits + c);
             xw[0] = xv.x, xw[1] = xv.y, xw[2] = xv.z, xw[3] = xv.w;
             sb = ((const uint2 *)S)[c];
             rv = (u64)r[i];
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void pc_party_kernel(int party, int variant, c
                 for (int k = 0; k < 4; k++) dw[k] = d2[k];
             }
         }
-        if (live) d_out[c] = make_uint4(dw[0], dw[1], dw[2], dw[3]);
+        if (live) st_stream(d_out + c, dw[0], dw[1], dw[2], dw[3]);
     }
 }
 
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256) void pc_helper_kernel(const uint4 *__restrict_
         const bool live = c < pieces;
         bool hit = false;
         if (live) {
-            const uint4 a = d0[c], b = d1[c];
+            const uint4 a = ld_stream(d0 + c), b = ld_stream(d1 + c);
             const u32 aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};
 #pragma unroll
             for (int j = 0; j < 8; j++) {
@@ -237,8 +237,8 @@ __global__ __launch_bounds__(256) void bit_share_kernel(const u64 *__restrict__ 
             a.set(j, s);
             b.set(j, (bit + P - s) % P);
         }
-        first[c] = make_uint4(a.w[0], a.w[1], a.w[2], a.w[3]);
-        second[c] = make_uint4(b.w[0], b.w[1], b.w[2], b.w[3]);
+        st_stream(first + c, a.w[0], a.w[1], a.w[2], a.w[3]);
+        st_stream(second + c, b.w[0], b.w[1], b.w[2], b.w[3]);
     }
 }
 
