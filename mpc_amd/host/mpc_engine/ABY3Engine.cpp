@@ -169,6 +169,13 @@ void ABY3Engine::matrix_mul(const array<MatrixXl, 2> &Xj, const array<MatrixXl, 
     Zj[1].resize(rows, cols);
     string2matrix(message_send[pe.prev], Zj[0]);
     string2matrix(message_recv[pe.next], Zj[1]);
+#if defined MYDEBUG // the product of the revealed operands (ABY3Engine.cpp:202-209)
+    MatrixXl xd, yd, zd;
+    reveal_matrix(Xj, xd);
+    reveal_matrix(Yj, yd);
+    reveal_matrix(Zj, zd);
+    assert(zd == xd * yd);
+#endif
 }
 
 void ABY3Engine::vector_mul(const array<VecI64, 2> &Xj, const array<VecI64, 2> &Yj, array<VecI64, 2> &Zj) {
@@ -188,6 +195,13 @@ void ABY3Engine::vector_mul(const array<VecI64, 2> &Xj, const array<VecI64, 2> &
     messenger->send_and_recv(message_send, message_recv);
     string2vecI64(message_send[pe.prev], Zj[0]);
     string2vecI64(message_recv[pe.next], Zj[1]);
+#if defined MYDEBUG // :231-241
+    VecI64 xd, yd, zd;
+    reveal(Xj, xd);
+    reveal(Yj, yd);
+    reveal(Zj, zd);
+    for (size_t i = 0; i < (size_t)zd.size(); i++) assert((uint64_t)zd[i] == (uint64_t)xd[i] * (uint64_t)yd[i]);
+#endif
 }
 
 void ABY3Engine::vecbool_mul(const array<vecbool, 2> &Xj, const array<vecbool, 2> &Yj, array<vecbool, 2> &Zj) {
@@ -204,6 +218,13 @@ void ABY3Engine::vecbool_mul(const array<vecbool, 2> &Xj, const array<vecbool, 2
     messenger->send_and_recv(message_send, message_recv);
     string2vecbool(message_send[pe.prev], Zj[0]);
     string2vecbool(message_recv[pe.next], Zj[1]);
+#if defined MYDEBUG // :261-270
+    vecbool xd, yd, zd;
+    reveal_bools(Xj, xd);
+    reveal_bools(Yj, yd);
+    reveal_bools(Zj, zd);
+    for (size_t i = 0; i < zd.size(); i++) assert(zd[i] == (xd[i] & yd[i]));
+#endif
 }
 
 // ---- carry-save step before msb: two rounds
@@ -229,6 +250,15 @@ void ABY3Engine::add_prepare(const array<VecI64, 2> &Xj, array<VecI64, 2> &Gj, a
     Pj[1].resize(n);
     p0.down(Pj[0].data(), n);
     p1.down(Pj[1].data(), n);
+#if defined MYDEBUG
+    // :327-345 asserts S + 2C = X, P = S ^ 2C, G = S & 2C on the revealed words; with S and 2C internal to the
+    // device segments the same statement reads X = (S ^ 2C) + 2 (S & 2C) = P + 2 G
+    VecI64 xd, gd, pd;
+    reveal(Xj, xd);
+    reveal_bits(Gj, gd);
+    reveal_bits(Pj, pd);
+    for (size_t i = 0; i < (size_t)xd.size(); i++) assert((uint64_t)xd[i] == (uint64_t)pd[i] + 2 * (uint64_t)gd[i]);
+#endif
 }
 
 // ---- most significant bit of the sum: 6 rounds of the carry tree
@@ -258,6 +288,16 @@ void ABY3Engine::msb(const array<VecI64, 2> &Gj, const array<VecI64, 2> &Pj, arr
     Zj[1].resize(n);
     z0.down(Zj[0].data(), n);
     z1.down(Zj[1].data(), n);
+#if defined MYDEBUG
+    // the carry tree's result: the sign bit of P + 2 G, the value add_prepare split (the per-level statements of
+    // :430-444 hold inside the device segments, which are checked level by level against the CPU restatement)
+    VecI64 gd, pd;
+    vecbool zd;
+    reveal_bits(Gj, gd);
+    reveal_bits(Pj, pd);
+    reveal_bools(Zj, zd);
+    for (size_t i = 0; i < zd.size(); i++) assert(zd[i] == (int8_t)(((uint64_t)pd[i] + 2 * (uint64_t)gd[i]) >> 63));
+#endif
 }
 
 void ABY3Engine::trunc(const array<VecI64, 2> &Xj, array<VecI64, 2> &Yj, size_t number) {
@@ -332,4 +372,12 @@ void ABY3Engine::bit_inject(const array<VecI64, 2> &Aj, const array<vecbool, 2> 
     Cj[1].resize(n);
     c0.down(Cj[0].data(), n);
     c1.down(Cj[1].data(), n);
+#if defined MYDEBUG // the reference checks the two OT outputs one by one (:1018-1037); their sum is C = A * b
+    VecI64 ad, cd;
+    vecbool bd;
+    reveal(Aj, ad);
+    reveal_bools(Bj, bd);
+    reveal(Cj, cd);
+    for (size_t i = 0; i < (size_t)cd.size(); i++) assert(cd[i] == (bd[i] ? ad[i] : 0));
+#endif
 }

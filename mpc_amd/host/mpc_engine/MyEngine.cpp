@@ -178,6 +178,15 @@ void MyEngine::reveal_zp(const vector<zpshare> &Xbits_j, vector<zpshare> &Xbits_
 
 // ---- Beaver products, one round: party 2 sends C_j, parties 0/1 swap E_j | F_j in the same round
 void MyEngine::matrix_mul(const MatrixXl &Xj, const MatrixXl &Yj, MatrixXl &Zj) {
+#if defined MYDEBUG
+    mpcgpu::AtExit check([&] {
+        MatrixXl xd, yd, zd;
+        reveal_matrix(Xj, xd);
+        reveal_matrix(Yj, yd);
+        reveal_matrix(Zj, zd);
+        assert(zd == xd * yd);
+    });
+#endif
     const size_t rows = Xj.rows(), lens = Xj.cols(), cols = Yj.cols();
     assert(Yj.rows() == lens);
     const size_t na = rows * lens, nb = lens * cols, nc = rows * cols;
@@ -209,6 +218,15 @@ void MyEngine::matrix_mul(const MatrixXl &Xj, const MatrixXl &Yj, MatrixXl &Zj) 
 }
 
 void MyEngine::vector_mul(const VecI64 &Xj, const VecI64 &Yj, VecI64 &Zj) {
+#if defined MYDEBUG
+    mpcgpu::AtExit check([&] {
+        VecI64 xd, yd, zd;
+        reveal(Xj, xd);
+        reveal(Yj, yd);
+        reveal(Zj, zd);
+        for (size_t i = 0; i < (size_t)zd.size(); i++) assert((uint64_t)zd[i] == (uint64_t)xd[i] * (uint64_t)yd[i]);
+    });
+#endif
     const size_t n = Xj.size();
     assert((size_t)Yj.size() == n);
     Zj.resize(n);
@@ -268,6 +286,15 @@ void MyEngine::privateCompare(const vector<zpshare> &Xbits_j, const vecbool &Bet
 
 // ---- msb of a in [-2^62, 2^62): three rounds, XOR-shared result
 void MyEngine::msb(const VecI64 &Aj, vecbool &Bj) {
+#if defined MYDEBUG // MyEngine.cpp:582: XOR shares of the sign bit
+    mpcgpu::AtExit check([&] {
+        VecI64 ad;
+        vecbool bd;
+        reveal(Aj, ad);
+        reveal_vec_bools(Bj, bd);
+        for (size_t i = 0; i < bd.size(); i++) assert(bd[i] == (int8_t)(ad[i] < 0));
+    });
+#endif
     const size_t n = Aj.size();
     Bj.assign(n, 0);
     if (party_id == 2) {
@@ -332,6 +359,16 @@ void MyEngine::msb(const VecI64 &Aj, vecbool &Bj) {
 
 // ---- x * a for an XOR-shared boolean a, one round
 void MyEngine::bit_inject(const VecI64 &Xj, const vecbool &Aj, VecI64 &Zj) {
+#if defined MYDEBUG // :752: Z = X * a
+    mpcgpu::AtExit check([&] {
+        VecI64 xd, zd;
+        vecbool ad;
+        reveal(Xj, xd);
+        reveal_vec_bools(Aj, ad);
+        reveal(Zj, zd);
+        for (size_t i = 0; i < (size_t)zd.size(); i++) assert(zd[i] == (ad[i] ? xd[i] : 0));
+    });
+#endif
     const size_t n = Xj.size();
     assert(Aj.size() == n);
     Zj.resize(n);

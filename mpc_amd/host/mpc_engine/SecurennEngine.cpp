@@ -26,6 +26,15 @@ SecurennEngine::~SecurennEngine() { mpcx_shutdown(gpu); }
 
 // ---- Beaver-triple matrix product: party 2 deals (A_i | B_i | C_i), parties 0/1 open E = X - A, F = Y - B
 void SecurennEngine::matrix_mul(const MatrixXl &Xj, const MatrixXl &Yj, MatrixXl &Zj) {
+#if defined MYDEBUG // the product of the opened operands (the statement SecurennEngine.cpp:218 makes for vector_mul)
+    mpcgpu::AtExit check([&] {
+        MatrixXl xd, yd, zd;
+        reveal_matrix(Xj, xd);
+        reveal_matrix(Yj, yd);
+        reveal_matrix(Zj, zd);
+        assert(zd == xd * yd);
+    });
+#endif
     const size_t rows = Xj.rows(), lens = Xj.cols(), cols = Yj.cols();
     assert(Yj.rows() == lens);
     const size_t na = rows * lens, nb = lens * cols, nc = rows * cols;
@@ -63,6 +72,15 @@ void SecurennEngine::matrix_mul(const MatrixXl &Xj, const MatrixXl &Yj, MatrixXl
 }
 
 void SecurennEngine::vector_mul(const vector<int64_t> &Xj, const vector<int64_t> &Yj, vector<int64_t> &Zj) {
+#if defined MYDEBUG // :218, :296
+    mpcgpu::AtExit check([&] {
+        vector<int64_t> xd, yd, zd;
+        reveal(Xj, xd);
+        reveal(Yj, yd);
+        reveal(Zj, zd);
+        for (size_t i = 0; i < zd.size(); i++) assert((uint64_t)zd[i] == (uint64_t)xd[i] * (uint64_t)yd[i]);
+    });
+#endif
     const size_t n = Xj.size();
     assert(Yj.size() == n);
     Zj.assign(n, 0);
@@ -429,6 +447,14 @@ void SecurennEngine::privateCompare(const vector<zpshare> &Xbits_j, const vector
 
 // ---- shareConvert: shares over Z_2^64 -> shares over Z_{2^64-1}, four rounds
 void SecurennEngine::shareConvert(const vector<int64_t> &Aj, vector<int64_t> &Yj) {
+#if defined MYDEBUG // :767, :876: the same value, now shared over Z_(2^64 - 1)
+    mpcgpu::AtExit check([&] {
+        vector<int64_t> ad, yd;
+        reveal(Aj, ad);
+        reveal_L_1(Yj, yd);
+        for (size_t i = 0; i < ad.size(); i++) assert((uint64_t)yd[i] == (uint64_t)ad[i] % L_1);
+    });
+#endif
     const size_t n = Aj.size();
     Yj.assign(n, 0);
     if (party_id == 2) {
@@ -442,6 +468,14 @@ void SecurennEngine::shareConvert(const vector<int64_t> &Aj, vector<int64_t> &Yj
 
 // ---- msb over Z_{2^64-1}, six rounds
 void SecurennEngine::msb_L_1(const vector<int64_t> &Aj, vector<int64_t> &Bj) {
+#if defined MYDEBUG // :961, :1038: the top bit of the value shared over Z_(2^64 - 1)
+    mpcgpu::AtExit check([&] {
+        vector<int64_t> ad, bd;
+        reveal_L_1(Aj, ad);
+        reveal(Bj, bd);
+        for (size_t i = 0; i < ad.size(); i++) assert((uint64_t)bd[i] == (uint64_t)ad[i] >> 63);
+    });
+#endif
     const size_t n = Aj.size();
     Bj.assign(n, 0);
     if (party_id == 2) {
@@ -455,6 +489,17 @@ void SecurennEngine::msb_L_1(const vector<int64_t> &Aj, vector<int64_t> &Bj) {
 
 // ---- msb of a in [-2^62, 2^62): convert 2a to Z_{2^64-1}, then msb_L_1; the intermediate stays on the device
 void SecurennEngine::msb(const vector<int64_t> &Aj, vector<int64_t> &Bj) {
+#if defined MYDEBUG // :1102 asserts the input range; the sign bit comes out
+    mpcgpu::AtExit check([&] {
+        vector<int64_t> ad, bd;
+        reveal(Aj, ad);
+        reveal(Bj, bd);
+        for (size_t i = 0; i < ad.size(); i++) {
+            assert(-((int64_t)1 << 62) <= ad[i] && ad[i] <= ((int64_t)1 << 62) - 1);
+            assert(bd[i] == (ad[i] < 0));
+        }
+    });
+#endif
     const size_t n = Aj.size();
     Bj.assign(n, 0);
     if (party_id == 2) {

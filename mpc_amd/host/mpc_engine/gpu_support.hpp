@@ -20,6 +20,18 @@
 
 namespace mpcgpu {
 
+#if defined MYDEBUG
+// Engines built with -DMYDEBUG (the reference's switch, mpc_engine/ABY3Engine.cpp:3) open their operands and results
+// after a protocol and assert the relation it computes.  The checks cost extra messenger rounds, so every party has
+// to be built the same way.  A method with several exits declares its check first; it runs when the method returns.
+template <class F> struct AtExit {
+    F f;
+    explicit AtExit(F fn) : f(fn) {}
+    AtExit(const AtExit &) = delete;
+    ~AtExit() { f(); }
+};
+#endif
+
 inline mpcx_ctx *open_context() {
     mpcx_ctx *ctx = nullptr;
     const char *dev = getenv("MPCX_DEVICE");

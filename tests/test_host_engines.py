@@ -57,3 +57,17 @@ def test_host_engines_selftest_and_known_answers():
     assert [kat[("aby3_matmul_64_Z0", j)] for j in range(3)] == g["Z_share0"]
     assert {kat[("aby3_matmul_64_Zplain", j)] for j in range(3)} == {g["Z_plain"]}
     assert [kat[("snn_msb_1000_B", j)] for j in range(2)] == GOLD["snn_msb_1000"]["B_share"]
+
+
+@pytest.mark.gpu
+def test_host_engines_with_protocol_self_checks():
+    """The same program over engines compiled with -DMYDEBUG (the reference's switch, mpc_engine/ABY3Engine.cpp:3):
+    every product, add_prepare, msb, bit_inject, shareConvert and msb_L_1 opens its operands and its result and asserts
+    the relation between them; the share checksums are the same as without the checks (openings draw no randomness)."""
+    exe = os.path.join(HOST, "host_selftest_checked")
+    assert os.path.exists(exe), "mpc_amd/host/host_selftest_checked missing: run __graft_entry__.build()"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    plain = subprocess.run([os.path.join(HOST, "host_selftest")], capture_output=True, text=True, timeout=300)
+    kat = lambda out: sorted(l for l in out.splitlines() if l.startswith("KAT "))
+    assert kat(r.stdout) == kat(plain.stdout) and kat(r.stdout)
