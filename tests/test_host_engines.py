@@ -25,6 +25,15 @@ def test_socket_messenger_large_rounds_do_not_deadlock(mib):
     assert "ok" in r.stdout
 
 
+def test_wire_codecs_round_trip_and_byte_positions():
+    """test/test1.cpp:97-155, :230-262: every codec gives its input back; plus the byte positions of the wire layouts."""
+    exe = os.path.join(HOST, "codec_selftest")
+    if not os.path.exists(exe):
+        pytest.skip("host tools not built")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and "all checks passed" in r.stdout, r.stdout + r.stderr
+
+
 def test_host_headers_keep_the_reference_surface():
     """Same class / method / member names as mpc_engine/ABY3Engine.hpp:24-54 and SecurennEngine.hpp:20-50."""
     a = open(os.path.join(HOST, "mpc_engine", "ABY3Engine.hpp")).read()
