@@ -279,3 +279,12 @@ def test_private_compare_range_beyond_32_bit_stream_offsets(gpu, orc):
     ints_o, bools_o = orc.prg_fill_buff(KEY01, 128 * nt - 700, 700)
     ints_g, bools_g = gpu.prg_fill_buff(KEY01, 128 * nt - 700, 700)
     assert np.array_equal(ints_g, ints_o) and np.array_equal(bools_g, bools_o)
+
+
+def test_l1_addition_corner_values(gpu, orc):
+    """add_L_1 (SecurennEngine.cpp:15-21) on every pair of 0, 1, 2^63 - 1, 2^63, 2^64 - 2, 2^64 - 1 and random words."""
+    corner = np.array([0, 1, (1 << 63) - 1, 1 << 63, (1 << 64) - 2, (1 << 64) - 1], dtype=np.uint64)
+    rng = np.random.default_rng(9)
+    a = np.concatenate([np.repeat(corner, 6), rng.integers(0, 1 << 64, 1000, dtype=np.uint64)]).view(np.int64)
+    b = np.concatenate([np.tile(corner, 6), rng.integers(0, 1 << 64, 1000, dtype=np.uint64)]).view(np.int64)
+    assert np.array_equal(gpu.snn_add_L1(a, b), orc.snn_add_L1(a, b))

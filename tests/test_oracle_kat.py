@@ -257,3 +257,28 @@ def test_aby3_vecmul_property(orc):
     w = pr.World(orc)
     Z = pr.aby3_reveal(w, pr.aby3_vecmul(w, pr.aby3_share(w, X, n), pr.aby3_share(w, Y, n), n))[0]
     assert np.array_equal(Z.view(np.uint64), X.view(np.uint64) * Y.view(np.uint64))
+
+
+def test_l1_arithmetic_properties(orc):
+    """test/test1.cpp:205-227 (add_L_1 / sub_L_1 undo one another) and the definition itself,
+    SecurennEngine.cpp:15-28: c = a + b, (c + (c < a)) % (2^64 - 1), against big-integer arithmetic."""
+    L1 = (1 << 64) - 1
+    rng = np.random.default_rng(8)
+    a = rng.integers(0, 1 << 64, 5000, dtype=np.uint64)
+    b = rng.integers(0, 1 << 64, 5000, dtype=np.uint64)
+    corner = np.array([0, 1, L1 - 1, L1, 1 << 63, (1 << 63) - 1], dtype=np.uint64)
+    a[:36] = np.repeat(corner, 6)
+    b[:36] = np.tile(corner, 6)
+    got = orc.snn_add_L1(a.view(np.int64), b.view(np.int64)).view(np.uint64)
+
+    def ref_add(x, y):
+        c = (x + y) & ((1 << 64) - 1)
+        return (c + (c < x)) % L1
+
+    assert [int(v) for v in got] == [ref_add(int(x), int(y)) for x, y in zip(a, b)]
+    # sub(a, b) = add(a, (L_1 - b) % L_1) undoes add(., b) on residues
+    am, bm = a % np.uint64(L1), b % np.uint64(L1)
+    s = orc.snn_add_L1(am.view(np.int64), bm.view(np.int64)).view(np.uint64)
+    neg = ((np.uint64(L1) - bm) % np.uint64(L1))
+    back = orc.snn_add_L1(s.view(np.int64), neg.view(np.int64)).view(np.uint64)
+    assert np.array_equal(back, am)
