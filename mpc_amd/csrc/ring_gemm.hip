@@ -378,6 +378,7 @@ static u64 part_chunk_len(int nparts, u64 l) {
 }
 
 u64 ring_gemm_ws_bytes(int nparts, u64 r, u64 l, u64 c) {
+    if (ring_gemm_use_rns(r, l, c)) return ring_gemm_rns_ws_bytes(nparts, r, l, c);
     const u64 Mp = round_up(r, RM), Np = round_up(c, RM), Kp = (u64)nparts * part_chunk_len(nparts, l);
     const u64 bytesA = 8 * Mp * Kp, bytesB = 8 * Np * Kp;
     return ((bytesA + 255) & ~255ull) + ((bytesB + 255) & ~255ull);
@@ -385,6 +386,8 @@ u64 ring_gemm_ws_bytes(int nparts, u64 r, u64 l, u64 c) {
 
 int ring_gemm_parts(mpcx_ctx *ctx, const GemmPart *parts, int nparts, u64 r, u64 l, u64 c, int layA, int layB,
                     const i64 *add, const i64 *sub, i64 *Z, int layZ, int accumulate) {
+    if (r && l && c && ring_gemm_use_rns(r, l, c))
+        return ring_gemm_parts_rns(ctx, parts, nparts, r, l, c, layA, layB, add, sub, Z, layZ, accumulate);
     MPCX_REQUIRE(r > 0 && l > 0 && c > 0, "ring gemm: empty operand (r=%llu l=%llu c=%llu)", (unsigned long long)r,
                  (unsigned long long)l, (unsigned long long)c);
     MPCX_REQUIRE(r < (1u << 30) && c < (1u << 30) && l < (1u << 30), "ring gemm: dimension too large");

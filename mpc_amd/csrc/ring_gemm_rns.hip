@@ -1,0 +1,443 @@
+// Exact Z_2^64 matrix product through a residue number system on the int8 matrix cores of gfx950.
+//
+// A ring element is read as the integer v = sum d_j 256^j of its eight signed base-256 digits (|v| < 2^63.01,
+// v = x mod 2^64).  The integer product X = sum_k v(a_k) v(b_k) has |X| <= K * 2^126.02.  For NP pairwise coprime
+// moduli m_i <= 251 with M = prod m_i > 2^144.9:
+//     split   : plane_i = v mod m_i as a signed byte in [-(m_i-1)/2, (m_i-1)/2]      (one pass over the operands)
+//     gemm    : acc_i = A_i * B_i^T in int32 (|acc_i| <= 125^2 K < 2^31), y_i = (acc_i mod m_i) * (M/m_i)^-1 mod m_i
+//               -- NP plain int8 products instead of the 36 digit-pair products of the positional form
+//     combine : X = sum_i y_i (M/m_i) - q M with q = round(sum_i y_i / m_i)  (|X| / M <= 2^-5.9, so the rounding
+//               is decided with a margin no float error can reach), everything taken mod 2^64.
+// K is limited to 8192 per accumulation chunk (all concatenated parts), as in the positional kernel.
+#include <cmath>
+#include <cstdlib>
+#include <mutex>
+
+#include "mpcx_internal.h"
+
+namespace {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+constexpr int NP = 19;
+constexpr u32 RNS_MODULI[NP] = {251, 241, 239, 233, 229, 227, 223, 211, 199, 197, 193, 191, 181, 179, 173, 167, 163, 157, 151};
+constexpr u32 TM = 256, TN = 256, RK = 32, SKB = 3; // block tile; 32 bytes of K per block, three K blocks per stage
+constexpr u32 KB_BYTES = (TM + TN) * RK;             // 16 KiB: one K block of the A and the B tile
+constexpr u32 STAGE_BYTES = SKB * KB_BYTES;          // 48 KiB
+
+struct RnsTab {
+    u32 m[NP];       // modulus
+    u32 magic32[NP]; // floor(2^32 / m) + 1: exact quotient of x < 2^24 by m as a high product
+    u64 magic40[NP]; // ceil(2^40 / m): exact quotient of any 32-bit x as (x * magic) >> 40
+    i32 clo[NP], chi[NP]; // 256^j mod m (symmetric) for j = 0..3 / 4..7, one signed byte each
+    u32 off_split[NP];    // a multiple of m above 8 * 128 * 127
+    u32 off_acc[NP];      // a multiple of m above 2^28
+    u32 inv[NP];          // (M / m)^-1 mod m
+    u64 cM[NP];           // (M / m) mod 2^64
+    float w[NP];          // 1 / m
+    u64 Mmod;             // M mod 2^64
+};
+
+const RnsTab &rns_tab() {
+    static RnsTab T;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        T.Mmod = 1;
+        for (int i = 0; i < NP; i++) T.Mmod *= RNS_MODULI[i];
+        for (int i = 0; i < NP; i++) {
+            const u32 m = RNS_MODULI[i];
+            T.m[i] = m;
+            T.magic32[i] = (u32)((1ull << 32) / m) + 1;
+            T.magic40[i] = ((1ull << 40) + m - 1) / m;
+            u32 pw = 1;
+            u32 lo = 0, hi = 0;
+            for (int j = 0; j < 8; j++) {
+                i32 c = (i32)pw;
+                if (c > (i32)(m / 2)) c -= (i32)m;
+                if (j < 4)
+                    lo |= ((u32)c & 0xFFu) << (8 * j);
+                else
+                    hi |= ((u32)c & 0xFFu) << (8 * (j - 4));
+                pw = (pw * 256u) % m;
+            }
+            T.clo[i] = (i32)lo;
+            T.chi[i] = (i32)hi;
+            T.off_split[i] = m * 1024u;
+            T.off_acc[i] = m * ((1u << 28) / m + 1);
+            u64 c64 = 1;
+            u32 cm = 1;
+            for (int j = 0; j < NP; j++)
+                if (j != i) {
+                    c64 *= RNS_MODULI[j];
+                    cm = (u32)(((u64)cm * (RNS_MODULI[j] % m)) % m);
+                }
+            T.cM[i] = c64;
+            u32 inv = 1;
+            while (((u64)inv * cm) % m != 1) inv++;
+            T.inv[i] = inv;
+            T.w[i] = 1.0f / (float)m;
+        }
+    });
+    return T;
+}
+
+struct SplitJob {
+    const u64 *src, *src2; // src2 (nullable) is added element-wise (mod 2^64) first
+    i8 *planes;
+    u64 O, so, sk, Op, koff, kcover; // kcover: K extent this job writes (zeros beyond its K)
+};
+struct SplitJobs {
+    SplitJob j[16];
+};
+
+// planes[i][kb][o][k%32] = v(src(o,k) (+ src2(o,k))) mod m_i, K-blocked like the positional planes; zeros outside
+// [0,O) x [0,K).  grid (kcover_max/64, max Op/64, jobs).
+template <bool KFAST>
+__global__ __launch_bounds__(256) void rns_split_kernel(SplitJobs jobs, u64 K, u64 Kp, RnsTab T) {
+    const SplitJob &J = jobs.j[blockIdx.z];
+    const u32 tid = threadIdx.x;
+    const u64 o0 = (u64)blockIdx.y * 64, k0 = (u64)blockIdx.x * 64;
+    if (o0 >= J.Op || k0 >= J.kcover) return;
+    const u64 *__restrict__ src = J.src, *__restrict__ src2 = J.src2;
+    const u64 O = J.O, so = J.so, sk = J.sk;
+    const u32 oo = ((tid >> 1) & 31) | ((tid >> 7) << 5), kc = (tid & 1) | ((tid >> 6) & 1) << 1;
+    u64 y[16];
+    if constexpr (KFAST) {
+        __shared__ u64 tile[64][65];
+        u64 v[16];
+#pragma unroll
+        for (u32 j = 0; j < 16; j++) {
+            const u64 o = o0 + (tid >> 6) + 4 * j, k = k0 + (tid & 63);
+            const bool in = o < O && k < K;
+            v[j] = in ? src[o * so + k] : 0;
+            if (src2 && in) v[j] += src2[o * so + k];
+        }
+#pragma unroll
+        for (u32 j = 0; j < 16; j++) tile[(tid >> 6) + 4 * j][tid & 63] = v[j];
+        __syncthreads();
+#pragma unroll
+        for (u32 q = 0; q < 16; q++) y[q] = tile[oo][kc * 16 + q];
+    } else {
+        const u64 o = o0 + oo;
+#pragma unroll
+        for (u32 q = 0; q < 16; q++) {
+            const u64 k = k0 + kc * 16 + q;
+            const bool in = o < O && k < K;
+            y[q] = in ? src[o * so + k * sk] : 0;
+            if (src2 && in) y[q] += src2[o * so + k * sk];
+        }
+    }
+    // the bytes of (x + 0x80..80) ^ 0x80..80 are the signed digits of x
+#pragma unroll
+    for (u32 q = 0; q < 16; q++) y[q] = (y[q] + 0x8080808080808080ull) ^ 0x8080808080808080ull;
+    const u64 kg = J.koff + k0 + kc * 16;
+    if (kg >= Kp) return; // the last 64-wide block of the padded K range may stick out (Kp is a multiple of 32)
+    i8 *dst = J.planes + ((kg >> 5) * J.Op + o0 + oo) * RK + (kg & 31);
+    const u64 plane_stride = J.Op * Kp;
+#pragma unroll 1
+    for (int i = 0; i < NP; i++) {
+        const u32 m = T.m[i], half = m >> 1, magic = T.magic32[i];
+        const i32 clo = T.clo[i], chi = T.chi[i], off = (i32)T.off_split[i];
+        u32 w[4];
+#pragma unroll
+        for (u32 d = 0; d < 4; d++) {
+            u32 packed = 0;
+#pragma unroll
+            for (u32 e = 0; e < 4; e++) {
+                const u64 yy = y[4 * d + e];
+                const u32 t = (u32)__builtin_amdgcn_sdot4((i32)(u32)(yy >> 32), chi,
+                                                          __builtin_amdgcn_sdot4((i32)(u32)yy, clo, off, false), false);
+                u32 r = t - __umulhi(t, magic) * m; // t < 2^19
+                r = r > half ? r - m : r;
+                packed |= (r & 0xFFu) << (8 * e);
+            }
+            w[d] = packed;
+        }
+        *(uint4 *)(dst + (u64)i * plane_stride) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
+// Y_i[m][n] = ((sum_k A_i[m][k] B_i[n][k]) mod m_i) * inv_i mod m_i as one byte, for modulus i = blockIdx.y and one
+// 256 x 256 block tile.  Eight waves as 2(M) x 4(N); a wave owns 128 x 64 outputs = 4 x 2 MFMA tiles (8 accumulators).
+// A stage is three K blocks (96 bytes of K) of the A and B tiles = 48 KiB, staged by LDS-DMA in 1-KiB pieces (six per
+// wave and stage, issued singly between MFMAs) into three buffers: while stage t is multiplied, stage t+1 has landed
+// or is landing and stage t+2 is being issued.  The XOR swizzle of the 16-byte halves is the positional kernel's.
+__global__ __launch_bounds__(512) void rns_gemm_kernel(const i8 *__restrict__ Apl, const i8 *__restrict__ Bpl,
+                                                       u8 *__restrict__ Y, u32 Mp, u32 Np, u32 nkb, u32 tiles_m, u32 tiles_n,
+                                                       RnsTab T) {
+    __shared__ __attribute__((aligned(1024))) i8 lds[3 * STAGE_BYTES];
+    const u32 tid = threadIdx.x, lane = tid & 63;
+    const u32 wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const u32 wm = wid >> 2, wn = wid & 3, lr = lane & 31, lh = lane >> 5;
+    const u32 mod_i = blockIdx.y;
+
+    // XCD-aware order: workgroups b, b+8, .. share an L2; give each XCD a contiguous run of tiles, walked in
+    // 4-row groups column by column
+    const u32 nwg = tiles_m * tiles_n;
+    const u32 bid = blockIdx.x;
+    const u32 qq = nwg / 8, rem = nwg % 8, xcd = bid % 8;
+    const u32 swz = (xcd < rem ? xcd * (qq + 1) : rem * (qq + 1) + (xcd - rem) * qq) + bid / 8;
+    const u32 GM = 4;
+    const u32 per_group = GM * tiles_n;
+    const u32 group = swz / per_group, in_group = swz % per_group;
+    const u32 first_m = group * GM;
+    const u32 gsz = (tiles_m - first_m < GM) ? tiles_m - first_m : GM;
+    const u32 tm = first_m + in_group % gsz, tn = in_group / gsz;
+
+    const i8 *Ai = Apl + (u64)mod_i * nkb * Mp * RK;
+    const i8 *Bi = Bpl + (u64)mod_i * nkb * Np * RK;
+
+    // staging plan: 48 pieces of 1 KiB per stage, 6 per wave: piece p -> K block p / 16, then A rows 32 (p % 16) ..
+    // (p % 16 < 8) or B rows 32 (p % 16 - 8) ..
+    const u32 lrow = lane >> 1;
+    const u32 lsrc = lrow * RK + (((lane & 1) ^ ((lrow >> 3) & 1)) << 4);
+    const i8 *gsrc[6];
+    u32 gstep[6], ldst[6];
+#pragma unroll
+    for (u32 q = 0; q < 6; q++) {
+        const u32 p = wid * 6 + q, kb = p >> 4, idx = p & 15;
+        if (idx < 8) {
+            gsrc[q] = Ai + ((u64)kb * Mp + (u64)tm * TM + idx * 32) * RK;
+            gstep[q] = SKB * Mp * RK;
+            ldst[q] = kb * KB_BYTES + idx * 1024;
+        } else {
+            gsrc[q] = Bi + ((u64)kb * Np + (u64)tn * TN + (idx - 8) * 32) * RK;
+            gstep[q] = SKB * Np * RK;
+            ldst[q] = kb * KB_BYTES + TM * RK + (idx - 8) * 1024;
+        }
+    }
+    auto stage_piece = [&](u32 buf, u32 q) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gsrc[q] + lsrc),
+                                         (__attribute__((address_space(3))) void *)(lds + buf * STAGE_BYTES + ldst[q]), 16,
+                                         0, 0);
+        gsrc[q] += gstep[q];
+    };
+    const u32 fsw = (lh ^ ((lr >> 3) & 1)) << 4;
+    const u32 a_off = (wm * 128 + lr) * RK + fsw;
+    const u32 b_off = TM * RK + (wn * 64 + lr) * RK + fsw;
+
+    v16i acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[a][b][r] = 0;
+
+    const u32 nst = nkb / SKB;
+#pragma unroll
+    for (u32 q = 0; q < 6; q++) stage_piece(0, q);
+    if (nst > 1) {
+#pragma unroll
+        for (u32 q = 0; q < 6; q++) stage_piece(1, q);
+        asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+#define MPCX_PIN() __builtin_amdgcn_sched_barrier(0)
+    u32 cur = 0;
+    for (u32 t = 0; t < nst; t++) {
+        const u32 fill = cur == 0 ? 2 : cur - 1; // buffer of stage t+2 (= of stage t-1, free since the last barrier)
+        const bool more = t + 2 < nst;
+        const i8 *base = lds + cur * STAGE_BYTES;
+        v4i a[4], b[2];
+#pragma unroll
+        for (u32 mi = 0; mi < 4; mi++) a[mi] = *(const v4i *)(base + a_off + mi * 32 * RK);
+#pragma unroll
+        for (u32 ni = 0; ni < 2; ni++) b[ni] = *(const v4i *)(base + b_off + ni * 32 * RK);
+#pragma unroll
+        for (u32 s = 0; s < SKB; s++) {
+            v4i an[4], bn[2];
+            if (s + 1 < SKB) {
+#pragma unroll
+                for (u32 mi = 0; mi < 4; mi++) an[mi] = *(const v4i *)(base + (s + 1) * KB_BYTES + a_off + mi * 32 * RK);
+#pragma unroll
+                for (u32 ni = 0; ni < 2; ni++) bn[ni] = *(const v4i *)(base + (s + 1) * KB_BYTES + b_off + ni * 32 * RK);
+            }
+#pragma unroll
+            for (u32 mi = 0; mi < 4; mi++) {
+#pragma unroll
+                for (u32 ni = 0; ni < 2; ni++)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+                if (mi & 1) { // after every fourth MFMA: one DMA piece of stage t+2
+                    MPCX_PIN();
+                    if (more) stage_piece(fill, 2 * s + (mi >> 1));
+                    MPCX_PIN();
+                }
+            }
+            if (s + 1 < SKB) {
+#pragma unroll
+                for (u32 mi = 0; mi < 4; mi++) a[mi] = an[mi];
+#pragma unroll
+                for (u32 ni = 0; ni < 2; ni++) b[ni] = bn[ni];
+            }
+        }
+        // stage t+1's six pieces are older than the six just issued
+        if (more)
+            asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        cur = cur == 2 ? 0 : cur + 1;
+    }
+#undef MPCX_PIN
+
+    // epilogue: acc mod m, times inv, mod m -> one byte
+    const u32 m = T.m[mod_i], inv = T.inv[mod_i], off = T.off_acc[mod_i];
+    const u64 magic = T.magic40[mod_i];
+    u8 *Yi = Y + (u64)mod_i * Mp * Np;
+#pragma unroll
+    for (u32 mi = 0; mi < 4; mi++)
+#pragma unroll
+        for (u32 ni = 0; ni < 2; ni++) {
+            const u32 col = tn * TN + wn * 64 + ni * 32 + lr;
+            const u32 row0 = tm * TM + wm * 128 + mi * 32 + 4 * lh;
+#pragma unroll
+            for (u32 r = 0; r < 16; r++) {
+                const u32 row = row0 + (r & 3) + 8 * (r >> 2);
+                u32 x = (u32)(acc[mi][ni][r] + (i32)off); // |acc| < 2^28 <= off
+                x -= (u32)(((u64)x * magic) >> 40) * m;
+                u32 yv = x * inv;
+                yv -= (u32)(((u64)yv * magic) >> 40) * m;
+                Yi[(u64)row * Np + col] = (u8)yv;
+            }
+        }
+}
+
+// Z[m][n] (+)= (sum_i y_i cM_i - round(sum_i y_i / m_i) Mmod) + add - sub, four columns per lane
+__global__ __launch_bounds__(256) void rns_combine_kernel(const u8 *__restrict__ Y, u64 Mp, u64 Np, u64 M, u64 N,
+                                                          const u64 *__restrict__ add, const u64 *__restrict__ sub,
+                                                          u64 *__restrict__ Z, u64 ldz_row, u64 ldz_col, int accumulate,
+                                                          RnsTab T) {
+    const u64 nq = (N + 3) / 4, total = M * nq;
+    const u64 plane = Mp * Np;
+    for (u64 it = (u64)blockIdx.x * 256 + threadIdx.x; it < total; it += (u64)gridDim.x * 256) {
+        const u64 row = it / nq, c0 = (it - row * nq) * 4;
+        const u8 *p = Y + row * Np + c0; // Np is a multiple of 256: the four bytes are one aligned word
+        u64 z[4] = {0, 0, 0, 0};
+        float f[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < NP; i++) {
+            const u32 w = *(const u32 *)(p + (u64)i * plane);
+#pragma unroll
+            for (u32 e = 0; e < 4; e++) {
+                const u32 yv = (w >> (8 * e)) & 0xFFu;
+                z[e] += (u64)yv * T.cM[i];
+                f[e] = fmaf((float)yv, T.w[i], f[e]);
+            }
+        }
+#pragma unroll
+        for (u32 e = 0; e < 4; e++) {
+            const u64 col = c0 + e;
+            if (col >= N) break;
+            u64 v = z[e] - (u64)(i64)rintf(f[e]) * T.Mmod;
+            const u64 idx = row * N + col;
+            if (add) v += add[idx];
+            if (sub) v -= sub[idx];
+            const u64 zi = row * ldz_row + col * ldz_col;
+            if (accumulate) v += Z[zi];
+            Z[zi] = v;
+        }
+    }
+}
+
+inline u64 round_up(u64 a, u64 b) { return ceil_div(a, b) * b; }
+constexpr u64 KPAD = 64, KSTAGE = SKB * RK; // 96
+
+u64 rns_part_chunk_len(int nparts, u64 l) {
+    const u64 max_kc = 8192;
+    u64 lc = round_up(l, KPAD);
+    while ((u64)nparts * lc > max_kc && lc > KPAD) lc = round_up(lc / 2, KPAD);
+    return lc;
+}
+
+} // namespace
+
+bool ring_gemm_use_rns(u64 r, u64 l, u64 c) {
+    static const int mode = getenv("MPCX_GEMM_RNS") ? atoi(getenv("MPCX_GEMM_RNS")) : 0;
+    if (mode == 0) return false;
+    if (mode == 2) return true; // every shape (tests)
+    return r >= 1024 && c >= 1024 && l >= 512;
+}
+
+u64 ring_gemm_rns_ws_bytes(int nparts, u64 r, u64 l, u64 c) {
+    const u64 Mp = round_up(r, TM), Np = round_up(c, TN);
+    const u64 Kp = round_up((u64)nparts * rns_part_chunk_len(nparts, l), KSTAGE);
+    const u64 a = (NP * Mp * Kp + 255) & ~255ull, b = (NP * Np * Kp + 255) & ~255ull, y = (NP * Mp * Np + 255) & ~255ull;
+    return a + b + y;
+}
+
+int ring_gemm_parts_rns(mpcx_ctx *ctx, const GemmPart *parts, int nparts, u64 r, u64 l, u64 c, int layA, int layB,
+                        const i64 *add, const i64 *sub, i64 *Z, int layZ, int accumulate) {
+    MPCX_REQUIRE(r > 0 && l > 0 && c > 0, "ring gemm: empty operand (r=%llu l=%llu c=%llu)", (unsigned long long)r,
+                 (unsigned long long)l, (unsigned long long)c);
+    MPCX_REQUIRE(r < (1u << 30) && c < (1u << 30) && l < (1u << 30), "ring gemm: dimension too large");
+    MPCX_REQUIRE(nparts >= 1 && nparts <= 8, "ring gemm: bad part count");
+    const RnsTab &T = rns_tab();
+    const u64 Mp = round_up(r, TM), Np = round_up(c, TN);
+    const u64 lc = rns_part_chunk_len(nparts, l);
+    const u64 Kp = round_up((u64)nparts * lc, KSTAGE);
+    MPCX_REQUIRE((u64)nparts * lc <= 8192, "ring gemm: cannot chunk K");
+    void *ws;
+    MPCX_TRY(mpcx_ws(ctx, ring_gemm_rns_ws_bytes(nparts, r, l, c), &ws));
+    i8 *Apl = (i8 *)ws;
+    i8 *Bpl = Apl + ((NP * Mp * Kp + 255) & ~255ull);
+    u8 *Y = (u8 *)Bpl + ((NP * Np * Kp + 255) & ~255ull);
+    const u32 tiles_m = (u32)(Mp / TM), tiles_n = (u32)(Np / TN);
+    const u32 nkb = (u32)(Kp / RK);
+    const u64 soA = layA ? 1 : l, skA = layA ? r : 1;
+    const u64 soB = layB ? l : 1, skB = layB ? 1 : c;
+    int first = 1;
+    for (u64 kb = 0; kb < l; kb += lc) {
+        const u64 klen = (l - kb < lc) ? l - kb : lc;
+        {
+            ProfScope ps(ctx, PROF_SPLIT);
+            SplitJobs fast, slow;
+            u32 nfast = 0, nslow = 0;
+            u64 fast_op = 0, slow_op = 0;
+            for (int p = 0; p < nparts; p++) {
+                // the last part also writes the zeros up to the stage-padded end of K
+                const u64 cover = p + 1 == nparts ? Kp - (u64)p * lc : lc;
+                const SplitJob ja{(const u64 *)parts[p].A + kb * skA, nullptr, Apl, r, soA, skA, Mp, (u64)p * lc, cover};
+                const SplitJob jb{(const u64 *)parts[p].B + kb * skB,
+                                  parts[p].Bplus ? (const u64 *)parts[p].Bplus + kb * skB : nullptr, Bpl, c, soB, skB, Np,
+                                  (u64)p * lc, cover};
+                for (const SplitJob &j : {ja, jb}) {
+                    if (j.sk == 1) {
+                        fast.j[nfast++] = j;
+                        if (j.Op > fast_op) fast_op = j.Op;
+                    } else {
+                        slow.j[nslow++] = j;
+                        if (j.Op > slow_op) slow_op = j.Op;
+                    }
+                }
+            }
+            const u32 gx = (u32)ceil_div(Kp - (u64)(nparts - 1) * lc, 64);
+            if (nfast)
+                hipLaunchKernelGGL(rns_split_kernel<true>, dim3(gx, (u32)(fast_op / 64), nfast), dim3(256), 0, ctx->stream,
+                                   fast, klen, Kp, T);
+            if (nslow)
+                hipLaunchKernelGGL(rns_split_kernel<false>, dim3(gx, (u32)(slow_op / 64), nslow), dim3(256), 0, ctx->stream,
+                                   slow, klen, Kp, T);
+        }
+        {
+            ProfScope ps(ctx, PROF_GEMM);
+            hipLaunchKernelGGL(rns_gemm_kernel, dim3(tiles_m * tiles_n, NP), dim3(512), 0, ctx->stream, Apl, Bpl, Y, (u32)Mp,
+                               (u32)Np, nkb, tiles_m, tiles_n, T);
+        }
+        {
+            ProfScope ps(ctx, PROF_SPLIT);
+            const bool last = kb + lc >= l;
+            const u64 *ad = last ? (const u64 *)add : nullptr, *sb = last ? (const u64 *)sub : nullptr;
+            const u64 ldr = layZ ? (u64)1 : c, ldc = layZ ? r : (u64)1;
+            const int acc = (accumulate || !first) ? 1 : 0;
+            u64 blocks = ceil_div(r * ((c + 3) / 4), 256);
+            if (blocks > MPCX_MAX_GRID) blocks = MPCX_MAX_GRID;
+            hipLaunchKernelGGL(rns_combine_kernel, dim3((u32)blocks), dim3(256), 0, ctx->stream, Y, Mp, Np, r, c, ad, sb,
+                               (u64 *)Z, ldr, ldc, acc, T);
+        }
+        first = 0;
+    }
+    MPCX_LAUNCH_CHECK();
+    return 0;
+}
