@@ -353,11 +353,15 @@ u64 rns_part_chunk_len(int nparts, u64 l) {
 
 } // namespace
 
+// MPCX_GEMM_RNS: 0 = never, 2 = every shape, otherwise (default) products large enough for the 19 tiled passes to
+// beat the positional kernel (measured crossover near 3000^3; below it the 256 x 256 tiles and the two extra passes cost
+// more than the saved multiplications).  Read on every call so that one process can exercise both paths.
 bool ring_gemm_use_rns(u64 r, u64 l, u64 c) {
-    static const int mode = getenv("MPCX_GEMM_RNS") ? atoi(getenv("MPCX_GEMM_RNS")) : 0;
+    const char *e = getenv("MPCX_GEMM_RNS");
+    const int mode = e ? atoi(e) : 1;
     if (mode == 0) return false;
-    if (mode == 2) return true; // every shape (tests)
-    return r >= 1024 && c >= 1024 && l >= 512;
+    if (mode == 2) return true;
+    return r * c >= 3072ull * 3072ull && l >= 1024;
 }
 
 u64 ring_gemm_rns_ws_bytes(int nparts, u64 r, u64 l, u64 c) {

@@ -97,6 +97,18 @@ def test_ring_gemm_random_shapes_and_layouts(gpu, orc):
         assert np.array_equal(got, want), f"shape {(r, l, c)} layouts {(la, lb, lc)} accumulate {acc}"
 
 
+@pytest.mark.parametrize("mode", ["0", "2"])
+def test_ring_gemm_both_formulations(gpu, orc, mode, monkeypatch):
+    """The positional (36 digit-pair products) and the residue (19 products + CRT) kernels, each forced for every
+    shape: random shapes and layouts, extreme digits with two K chunks, accumulation, and the tile-ragged large case."""
+    monkeypatch.setenv("MPCX_GEMM_RNS", mode)
+    test_ring_gemm_random_shapes_and_layouts(gpu, orc)
+    test_ring_gemm_extreme_digits(gpu, orc)
+    test_ring_gemm_accumulate_and_mixed_layouts(gpu, orc)
+    for r, l, c, lay in ((129, 130, 131, 0), (300, 17, 260, 1), (600, 130, 520, 0), (257, 97, 255, 1)):
+        test_ring_gemm_parity(gpu, orc, r, l, c, lay)
+
+
 def test_relayout(gpu):
     a = np.arange(37 * 91, dtype=np.int64)
     assert np.array_equal(gpu.relayout(a, 37, 91, 0, 1), np.ascontiguousarray(a.reshape(37, 91).T).ravel())

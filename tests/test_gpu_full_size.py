@@ -139,10 +139,11 @@ def test_aby3_relu_chain_2_28_in_batches(env):
             assert torch.equal(up(C[j][1]), up(C[(j + 1) % 3][0])), f"range {b}: replicated shares disagree"
 
 
-@pytest.mark.parametrize("lay", [0, 1])
-def test_ring_gemm_ragged_large(env, lay):
+@pytest.mark.parametrize("lay,mode", [(0, "0"), (1, "0"), (0, "2"), (1, "2")])
+def test_ring_gemm_ragged_large(env, lay, mode, monkeypatch):
     """A 3001 x 5003 . 5003 x 2005 ring product (no dimension a multiple of the tile sizes; two K chunks when the parts
     are concatenated), in both layouts and accumulating onto a previous result: Z v = C v + A (B v) over Z_2^64."""
+    monkeypatch.setenv("MPCX_GEMM_RNS", mode)  # "0": digit-pair kernel, "2": residue kernel
     ctx, torch, dev, _ = env
     r, l, c = 3001, 5003, 2005
     rng = np.random.default_rng(77 + lay)
