@@ -1,13 +1,14 @@
 // Exact Z_2^64 matrix product through a residue number system on the int8 matrix cores of gfx950.
 //
 // A ring element is read as the integer v = sum d_j 256^j of its eight signed base-256 digits (|v| < 2^63.01,
-// v = x mod 2^64).  The integer product X = sum_k v(a_k) v(b_k) has |X| <= K * 2^126.02.  For NP pairwise coprime
-// moduli m_i <= 251 with M = prod m_i > 2^144.9:
-//     split   : plane_i = v mod m_i as a signed byte in [-(m_i-1)/2, (m_i-1)/2]      (one pass over the operands)
-//     gemm    : acc_i = A_i * B_i^T in int32 (|acc_i| <= 125^2 K < 2^31), y_i = (acc_i mod m_i) * (M/m_i)^-1 mod m_i
+// v = x mod 2^64).  The integer product X = sum_k v(a_k) v(b_k) has |X| <= K * 2^126.023.  For the NP = 18 largest
+// pairwise coprime moduli m_i <= 256 (M = prod m_i = 2^140.45):
+//     split   : plane_i = a signed byte congruent to v mod m_i, |.| <= 128            (one pass over the operands)
+//     gemm    : acc_i = A_i * B_i^T in int32 (|acc_i| <= 2^14 K < 2^28), y_i = (acc_i mod m_i) * (M/m_i)^-1 mod m_i
 //               -- NP plain int8 products instead of the 36 digit-pair products of the positional form
-//     combine : X = sum_i y_i (M/m_i) - q M with q = round(sum_i y_i / m_i)  (|X| / M <= 2^-5.9, so the rounding
-//               is decided with a margin no float error can reach), everything taken mod 2^64.
+//     combine : X = sum_i y_i (M/m_i) - q M with q = round(sum_i y_i / m_i): for K <= 8192 |X| / M <= 0.369, so the
+//               fraction of the float sum stays 0.13 away from one half, five orders above its rounding error;
+//               everything is then taken mod 2^64.
 // K is limited to 8192 per accumulation chunk (all concatenated parts), as in the positional kernel.
 #include <cmath>
 #include <cstdlib>
@@ -20,18 +21,17 @@ namespace {
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
-constexpr int NP = 19;
-constexpr u32 RNS_MODULI[NP] = {251, 241, 239, 233, 229, 227, 223, 211, 199, 197, 193, 191, 181, 179, 173, 167, 163, 157, 151};
+constexpr int NP = 18;
+// 256, 255 = 3*5*17, 253 = 11*23, 247 = 13*19, 217 = 7*31 and primes: no common factors
+constexpr u32 RNS_MODULI[NP] = {256, 255, 253, 251, 247, 241, 239, 233, 229, 227, 223, 217, 211, 199, 197, 193, 191, 181};
 constexpr u32 TM = 256, TN = 256, RK = 32, SKB = 3; // block tile; 32 bytes of K per block, three K blocks per stage
 constexpr u32 KB_BYTES = (TM + TN) * RK;             // 16 KiB: one K block of the A and the B tile
 constexpr u32 STAGE_BYTES = SKB * KB_BYTES;          // 48 KiB
 
 struct RnsTab {
     u32 m[NP];       // modulus
-    u32 magic32[NP]; // floor(2^32 / m) + 1: exact quotient of x < 2^24 by m as a high product
     u64 magic40[NP]; // ceil(2^40 / m): exact quotient of any 32-bit x as (x * magic) >> 40
     i32 clo[NP], chi[NP]; // 256^j mod m (symmetric) for j = 0..3 / 4..7, one signed byte each
-    u32 off_split[NP];    // a multiple of m above 8 * 128 * 127
     u32 off_acc[NP];      // a multiple of m above 2^28
     u32 inv[NP];          // (M / m)^-1 mod m
     u64 cM[NP];           // (M / m) mod 2^64
@@ -48,7 +48,6 @@ const RnsTab &rns_tab() {
         for (int i = 0; i < NP; i++) {
             const u32 m = RNS_MODULI[i];
             T.m[i] = m;
-            T.magic32[i] = (u32)((1ull << 32) / m) + 1;
             T.magic40[i] = ((1ull << 40) + m - 1) / m;
             u32 pw = 1;
             u32 lo = 0, hi = 0;
@@ -63,7 +62,6 @@ const RnsTab &rns_tab() {
             }
             T.clo[i] = (i32)lo;
             T.chi[i] = (i32)hi;
-            T.off_split[i] = m * 1024u;
             T.off_acc[i] = m * ((1u << 28) / m + 1);
             u64 c64 = 1;
             u32 cm = 1;
@@ -135,26 +133,28 @@ __global__ __launch_bounds__(256) void rns_split_kernel(SplitJobs jobs, u64 K, u
     if (kg >= Kp) return; // the last 64-wide block of the padded K range may stick out (Kp is a multiple of 32)
     i8 *dst = J.planes + ((kg >> 5) * J.Op + o0 + oo) * RK + (kg & 31);
     const u64 plane_stride = J.Op * Kp;
+    // residue: t = sum d_j (256^j mod m) (|t| <= 8 * 128 * 128), minus m times the nearest integer to t / m taken in
+    // float: the quotient is off by one only within 1e-4 of a tie, so |r| <= m/2 + 0.03, a signed byte (for m = 256
+    // the two ties +-128 are the same residue).
 #pragma unroll 1
     for (int i = 0; i < NP; i++) {
-        const u32 m = T.m[i], half = m >> 1, magic = T.magic32[i];
-        const i32 clo = T.clo[i], chi = T.chi[i], off = (i32)T.off_split[i];
-        u32 w[4];
+        const i32 m = (i32)T.m[i], clo = T.clo[i], chi = T.chi[i];
+        const float w = T.w[i];
+        u32 wd[4];
 #pragma unroll
         for (u32 d = 0; d < 4; d++) {
             u32 packed = 0;
 #pragma unroll
             for (u32 e = 0; e < 4; e++) {
                 const u64 yy = y[4 * d + e];
-                const u32 t = (u32)__builtin_amdgcn_sdot4((i32)(u32)(yy >> 32), chi,
-                                                          __builtin_amdgcn_sdot4((i32)(u32)yy, clo, off, false), false);
-                u32 r = t - __umulhi(t, magic) * m; // t < 2^19
-                r = r > half ? r - m : r;
-                packed |= (r & 0xFFu) << (8 * e);
+                const i32 t = __builtin_amdgcn_sdot4((i32)(u32)(yy >> 32), chi,
+                                                     __builtin_amdgcn_sdot4((i32)(u32)yy, clo, 0, false), false);
+                const i32 r = t - (i32)rintf((float)t * w) * m;
+                packed |= ((u32)r & 0xFFu) << (8 * e);
             }
-            w[d] = packed;
+            wd[d] = packed;
         }
-        *(uint4 *)(dst + (u64)i * plane_stride) = make_uint4(w[0], w[1], w[2], w[3]);
+        *(uint4 *)(dst + (u64)i * plane_stride) = make_uint4(wd[0], wd[1], wd[2], wd[3]);
     }
 }
 
@@ -236,49 +236,60 @@ __global__ __launch_bounds__(512) void rns_gemm_kernel(const i8 *__restrict__ Ap
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     }
 #define MPCX_PIN() __builtin_amdgcn_sched_barrier(0)
-    u32 cur = 0;
-    for (u32 t = 0; t < nst; t++) {
-        const u32 fill = cur == 0 ? 2 : cur - 1; // buffer of stage t+2 (= of stage t-1, free since the last barrier)
-        const bool more = t + 2 < nst;
-        const i8 *base = lds + cur * STAGE_BYTES;
-        v4i a[4], b[2];
+    auto rdA = [&](u32 buf, u32 s, u32 mi) { return *(const v4i *)(lds + buf * STAGE_BYTES + s * KB_BYTES + a_off + mi * 32 * RK); };
+    auto rdB = [&](u32 buf, u32 s, u32 ni) { return *(const v4i *)(lds + buf * STAGE_BYTES + s * KB_BYTES + b_off + ni * 32 * RK); };
+    // 8 MFMAs of one K block; a DMA piece of stage t+2 after the fourth and the eighth
+    auto block = [&](const v4i(&a)[4], const v4i(&b)[2], bool more, u32 fill, u32 q0) {
 #pragma unroll
-        for (u32 mi = 0; mi < 4; mi++) a[mi] = *(const v4i *)(base + a_off + mi * 32 * RK);
+        for (u32 mi = 0; mi < 4; mi++) {
 #pragma unroll
-        for (u32 ni = 0; ni < 2; ni++) b[ni] = *(const v4i *)(base + b_off + ni * 32 * RK);
-#pragma unroll
-        for (u32 s = 0; s < SKB; s++) {
-            v4i an[4], bn[2];
-            if (s + 1 < SKB) {
-#pragma unroll
-                for (u32 mi = 0; mi < 4; mi++) an[mi] = *(const v4i *)(base + (s + 1) * KB_BYTES + a_off + mi * 32 * RK);
-#pragma unroll
-                for (u32 ni = 0; ni < 2; ni++) bn[ni] = *(const v4i *)(base + (s + 1) * KB_BYTES + b_off + ni * 32 * RK);
-            }
-#pragma unroll
-            for (u32 mi = 0; mi < 4; mi++) {
-#pragma unroll
-                for (u32 ni = 0; ni < 2; ni++)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
-                if (mi & 1) { // after every fourth MFMA: one DMA piece of stage t+2
-                    MPCX_PIN();
-                    if (more) stage_piece(fill, 2 * s + (mi >> 1));
-                    MPCX_PIN();
-                }
-            }
-            if (s + 1 < SKB) {
-#pragma unroll
-                for (u32 mi = 0; mi < 4; mi++) a[mi] = an[mi];
-#pragma unroll
-                for (u32 ni = 0; ni < 2; ni++) b[ni] = bn[ni];
+            for (u32 ni = 0; ni < 2; ni++)
+                acc[mi][ni] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+            if (mi & 1) {
+                MPCX_PIN();
+                if (more) stage_piece(fill, q0 + (mi >> 1));
+                MPCX_PIN();
             }
         }
-        // stage t+1's six pieces are older than the six just issued
+    };
+    // One barrier per stage, placed after the second K block: by then every wave holds all fragments of stage t and
+    // its pieces of stage t+1 have landed, so the first fragments of stage t+1 are read while the third K block is
+    // multiplied and the matrix pipe never waits for LDS right after a barrier.  Stage t+2 goes to the buffer of
+    // stage t-1, free since the previous barrier.
+    v4i a0[4], b0[2];
+#pragma unroll
+    for (u32 mi = 0; mi < 4; mi++) a0[mi] = rdA(0, 0, mi);
+#pragma unroll
+    for (u32 ni = 0; ni < 2; ni++) b0[ni] = rdB(0, 0, ni);
+    u32 cur = 0;
+    for (u32 t = 0; t < nst; t++) {
+        const u32 nxt = cur == 2 ? 0 : cur + 1;
+        const u32 fill = cur == 0 ? 2 : cur - 1;
+        const bool more = t + 2 < nst;
+        v4i a1[4], b1[2], a2[4], b2[2];
+#pragma unroll
+        for (u32 mi = 0; mi < 4; mi++) a1[mi] = rdA(cur, 1, mi);
+#pragma unroll
+        for (u32 ni = 0; ni < 2; ni++) b1[ni] = rdB(cur, 1, ni);
+        block(a0, b0, more, fill, 0);
+#pragma unroll
+        for (u32 mi = 0; mi < 4; mi++) a2[mi] = rdA(cur, 2, mi);
+#pragma unroll
+        for (u32 ni = 0; ni < 2; ni++) b2[ni] = rdB(cur, 2, ni);
+        block(a1, b1, more, fill, 2);
+        // stage t+1's six pieces are older than the four just issued
         if (more)
-            asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         else
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        cur = cur == 2 ? 0 : cur + 1;
+        if (t + 1 < nst) {
+#pragma unroll
+            for (u32 mi = 0; mi < 4; mi++) a0[mi] = rdA(nxt, 0, mi);
+#pragma unroll
+            for (u32 ni = 0; ni < 2; ni++) b0[ni] = rdB(nxt, 0, ni);
+        }
+        block(a2, b2, more, fill, 4);
+        cur = nxt;
     }
 #undef MPCX_PIN
 
