@@ -41,14 +41,16 @@ def pair_seed(a, b):
     return {frozenset((0, 1)): KEY01, frozenset((1, 2)): KEY12, frozenset((0, 2)): KEY20}[frozenset((a, b))]
 
 
-def measured_traffic(n, world):
+def measured_traffic(n, world, kernel="limb_gemm_kernel"):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE doubled
     as gfx950 requires, + WRITE_SIZE); they were taken on the default single-GPU workload only."""
     path = os.path.join(ROOT, "profiles", "r1_pmc_summary.json")
     if n != 4096 or world != 1 or not os.path.exists(path):
         return None
-    d = json.load(open(path))["limb_gemm_kernel"]["derived"]
-    return d["hbm_read_bytes_per_launch"] + d["hbm_write_bytes_per_launch"]
+    d = json.load(open(path)).get(kernel)
+    if not d or "derived" not in d:
+        return None
+    return d["derived"]["hbm_read_bytes_per_launch"] + d["derived"]["hbm_write_bytes_per_launch"]
 
 
 def prof_read(ctx, name):
@@ -529,12 +531,19 @@ def main():
             dist.all_gather_object(bitwise, mine)
     if rank == 0:
         value = job.ring_ops_per_step() * args.steps / dt / 1e9
-        # dominant kernel: the int8-limb MFMA GEMM.  Algorithmic work per launch: 36 limb pairs x 2 ops x
-        # rows x c x K with K = 2l (the two ring products X0*(Y0+Y1) and X1*Y0 concatenated along K)
+        # dominant kernel: the int8 MFMA GEMM.  Algorithmic work per product (the positional formulation the metric is
+        # defined on): 36 digit pairs x 2 ops x rows x c x K with K = 2l (the two ring products X0*(Y0+Y1) and X1*Y0
+        # concatenated along K).  The library may reach the same exact result with fewer int8 products (18 residue
+        # products + CRT): `issued` is what the matrix cores actually executed.
         # (products with 2l > 8192 run as several K-chunk launches: count the work per product, not per launch)
         ops_per_product = 36 * 2 * job.rows * job.c * (2 * job.l)
+        import mpc_amd
+        nprod = mpc_amd.load_library().mpcx_ring_gemm_products(ctypes.c_uint64(job.rows), ctypes.c_uint64(job.l),
+                                                               ctypes.c_uint64(job.c))
+        kernel = "rns_gemm_kernel" if nprod == 18 else "limb_gemm_kernel"
         avg_s = gemm_ms / gemm_cnt * 1e-3
         achieved = ops_per_product * 3 * args.steps / (gemm_ms * 1e-3) / 1e12
+        issued = achieved * nprod / 36
         res = {
             "metric": "Z_2^64 share-matmul Gop/s + MSB/privateCompare elems/sec at 1/2/4/8 GPUs",
             "value": value, "unit": "Gop/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -544,11 +553,15 @@ def main():
                                    "3 parties per step (share_matrix x2, matrix_mul local, reveal_matrix), "
                                    "inputs from PRgenerator(20,0)",
                        "rows_per_gpu": job.rows, "parallelism": f"row-block x{world}" if world > 1 else "single GPU"},
-            "roofline": {"bound": "mfma", "kernel": "limb_gemm_kernel", "achieved": achieved, "peak": INT8_PEAK_TOPS,
-                         "unit": "TFLOP/s", "frac": achieved / INT8_PEAK_TOPS, "traffic": measured_traffic(args.size, world),
+            "roofline": {"bound": "mfma", "kernel": kernel, "achieved": achieved, "peak": INT8_PEAK_TOPS,
+                         "unit": "TFLOP/s", "frac": achieved / INT8_PEAK_TOPS,
+                         "issued": issued, "issued_frac": issued / INT8_PEAK_TOPS, "int8_products_per_multiply_add": nprod,
+                         "traffic": measured_traffic(args.size, world, kernel),
                          "traffic_unit": "bytes per launch (profiles/r1_pmc_summary.json)",
                          "avg_launch_ms": avg_s * 1e3, "launches": gemm_cnt,
-                         "note": "int8 TOP/s: 36 limb pairs x 2 x rows x c x 2l per product, over the summed launch time"},
+                         "note": "achieved = algorithmic int8 TOP/s: 36 digit pairs x 2 x rows x c x 2l per product over the "
+                                 "summed launch time of the GEMM kernel; issued = the int8 operations the kernel executes "
+                                 "(18 residue products instead of 36 digit-pair products when the residue formulation runs)"},
             "kernel_ms_per_step": breakdown,
         }
         if bitwise is not None:

@@ -80,9 +80,13 @@ int mpcx_set_rand_cache(mpcx_ctx *ctx, uint64_t max_bytes);
 int mpcx_prg_state_at_pop(mpcx_ctx *ctx, uint64_t seed, uint64_t lcg, uint64_t pop_index, uint64_t state_out[3]);
 
 /* ---- Z_2^64 helpers (Eigen int64 operator+,-,* as the engines use them) ---- */
-/* C (+)= A*B mod 2^64 on int8-limb MFMA; A is r x l, B is l x c */
+/* C (+)= A*B mod 2^64 on the int8 matrix cores (exact: signed base-256 digits, or residues + CRT); A is r x l, B is l x c */
 int mpcx_ring_gemm_u64(mpcx_ctx *ctx, const int64_t *A, const int64_t *B, int64_t *C, uint64_t r, uint64_t l,
                        uint64_t c, int layoutA, int layoutB, int layoutC, int accumulate);
+/* int8 products the library issues per ring multiply-add of an r x l . l x c product: 36 (digit pairs of the
+ * positional form) or 18 (residues modulo 18 coprime moduli + CRT), chosen by size; MPCX_GEMM_RNS=0 / 2 in the
+ * environment forces the first / the second.  No counterpart in the reference (Eigen's operator*). */
+int mpcx_ring_gemm_products(uint64_t r, uint64_t l, uint64_t c);
 int mpcx_ring_add(mpcx_ctx *ctx, const int64_t *a, const int64_t *b, int64_t *out, uint64_t n);
 int mpcx_ring_sub(mpcx_ctx *ctx, const int64_t *a, const int64_t *b, int64_t *out, uint64_t n);
 int mpcx_ring_sar(mpcx_ctx *ctx, const int64_t *a, int64_t *out, uint64_t n, int k); /* benchmark/benchmark1.cpp:106-112 */

@@ -472,6 +472,8 @@ int mpcx_ring_gemm_u64(mpcx_ctx *ctx, const int64_t *A, const int64_t *B, int64_
     return ring_gemm_parts(ctx, &p, 1, r, l, c, layoutA, layoutB, nullptr, nullptr, C, layoutC, accumulate);
 }
 
+int mpcx_ring_gemm_products(uint64_t r, uint64_t l, uint64_t c) { return ring_gemm_use_rns(r, l, c) ? 18 : 36; }
+
 int mpcx_relayout(mpcx_ctx *ctx, const int64_t *src, int64_t *dst, uint64_t rows, uint64_t cols, int lay_src,
                   int lay_dst) {
     MPCX_REQUIRE(src && dst && src != dst, "mpcx_relayout: bad pointers (in-place is not supported)");

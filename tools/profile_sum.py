@@ -16,7 +16,7 @@ for tag in ("pmc_rd", "pmc_wr", "pmc_sq"):
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"]
-            if any(s in k for s in ("limb_gemm", "split_limbs", "combine_kernel")):
+            if any(s in k for s in ("limb_gemm", "split_limbs", "rns_")):
                 dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
                 agg[(k.split("(")[0][-40:], r["Counter_Name"])].append((float(r["Counter_Value"]), dur))
         print("==", tag)
