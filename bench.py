@@ -548,7 +548,7 @@ def main():
             "metric": "Z_2^64 share-matmul Gop/s + MSB/privateCompare elems/sec at 1/2/4/8 GPUs",
             "value": value, "unit": "Gop/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u64 ring via int8 limbs (int32 accumulate)", "data": "synthetic",
+            "dtype": "u64 ring via int8 residues or digits (int32 accumulate)", "data": "synthetic",
             "config": {"workload": f"ABY3 {job.rows_total}x{job.l} . {job.l}x{job.c} Z_2^64 share matmul + reconstruct, "
                                    "3 parties per step (share_matrix x2, matrix_mul local, reveal_matrix), "
                                    "inputs from PRgenerator(20,0)",
