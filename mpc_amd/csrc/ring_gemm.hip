@@ -397,6 +397,7 @@ int ring_gemm_parts(mpcx_ctx *ctx, const GemmPart *parts, int nparts, u64 r, u64
     const u64 lc = part_chunk_len(nparts, l); // per-part chunk length along l
     const u64 Kp = (u64)nparts * lc;
     MPCX_REQUIRE(Kp <= 8192, "ring gemm: cannot chunk K");
+    MPCX_REQUIRE(Mp / 64 <= 65535 && Np / 64 <= 65535, "ring gemm: more than 4194240 rows or columns"); // split grid y
     const u64 bytesA = 8 * Mp * Kp, bytesB = 8 * Np * Kp;
     void *ws;
     MPCX_TRY(mpcx_ws(ctx, ring_gemm_ws_bytes(nparts, r, l, c), &ws));

@@ -393,6 +393,8 @@ int ring_gemm_parts_rns(mpcx_ctx *ctx, const GemmPart *parts, int nparts, u64 r,
     const u64 lc = rns_part_chunk_len(nparts, l);
     const u64 Kp = round_up((u64)nparts * lc, KSTAGE);
     MPCX_REQUIRE((u64)nparts * lc <= 8192, "ring gemm: cannot chunk K");
+    // the split grid has one y block per 64 rows, and the kernels step through the planes with 32-bit byte offsets
+    MPCX_REQUIRE(Mp / 64 <= 65535 && Np / 64 <= 65535, "ring gemm: more than 4194240 rows or columns");
     void *ws;
     MPCX_TRY(mpcx_ws(ctx, ring_gemm_rns_ws_bytes(nparts, r, l, c), &ws));
     i8 *Apl = (i8 *)ws;
