@@ -238,19 +238,22 @@ __global__ __launch_bounds__(512) void rns_gemm_kernel(const i8 *__restrict__ Ap
 #define MPCX_PIN() __builtin_amdgcn_sched_barrier(0)
     auto rdA = [&](u32 buf, u32 s, u32 mi) { return *(const v4i *)(lds + buf * STAGE_BYTES + s * KB_BYTES + a_off + mi * 32 * RK); };
     auto rdB = [&](u32 buf, u32 s, u32 ni) { return *(const v4i *)(lds + buf * STAGE_BYTES + s * KB_BYTES + b_off + ni * 32 * RK); };
-    // 8 MFMAs of one K block; a DMA piece of stage t+2 after the fourth and the eighth
-    auto block = [&](const v4i(&a)[4], const v4i(&b)[2], bool more, u32 fill, u32 q0) {
+    // 8 MFMAs of one K block with up to three DMA pieces of stage t+2 between them (after the 2nd, 5th and 8th)
+    auto block = [&](const v4i(&a)[4], const v4i(&b)[2], bool more, u32 fill, u32 q0, u32 nq) {
+        u32 n = 0, q = 0;
 #pragma unroll
-        for (u32 mi = 0; mi < 4; mi++) {
+        for (u32 mi = 0; mi < 4; mi++)
 #pragma unroll
-            for (u32 ni = 0; ni < 2; ni++)
+            for (u32 ni = 0; ni < 2; ni++) {
                 acc[mi][ni] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
-            if (mi & 1) {
-                MPCX_PIN();
-                if (more) stage_piece(fill, q0 + (mi >> 1));
-                MPCX_PIN();
+                n++;
+                if ((n == 2 || n == 5 || n == 8) && q < nq) {
+                    MPCX_PIN();
+                    if (more) stage_piece(fill, q0 + q);
+                    MPCX_PIN();
+                    q++;
+                }
             }
-        }
     };
     // One barrier per stage, placed after the second K block: by then every wave holds all fragments of stage t and
     // its pieces of stage t+1 have landed, so the first fragments of stage t+1 are read while the third K block is
@@ -271,15 +274,15 @@ __global__ __launch_bounds__(512) void rns_gemm_kernel(const i8 *__restrict__ Ap
         for (u32 mi = 0; mi < 4; mi++) a1[mi] = rdA(cur, 1, mi);
 #pragma unroll
         for (u32 ni = 0; ni < 2; ni++) b1[ni] = rdB(cur, 1, ni);
-        block(a0, b0, more, fill, 0);
+        block(a0, b0, more, fill, 0, 3);
 #pragma unroll
         for (u32 mi = 0; mi < 4; mi++) a2[mi] = rdA(cur, 2, mi);
 #pragma unroll
         for (u32 ni = 0; ni < 2; ni++) b2[ni] = rdB(cur, 2, ni);
-        block(a1, b1, more, fill, 2);
-        // stage t+1's six pieces are older than the four just issued
+        block(a1, b1, more, fill, 3, 3);
+        // stage t+1's six pieces are older than the six just issued
         if (more)
-            asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         else
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (t + 1 < nst) {
@@ -288,7 +291,7 @@ __global__ __launch_bounds__(512) void rns_gemm_kernel(const i8 *__restrict__ Ap
 #pragma unroll
             for (u32 ni = 0; ni < 2; ni++) b0[ni] = rdB(nxt, 0, ni);
         }
-        block(a2, b2, more, fill, 4);
+        block(a2, b2, more, fill, 6, 0);
         cur = nxt;
     }
 #undef MPCX_PIN
