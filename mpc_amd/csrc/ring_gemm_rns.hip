@@ -143,16 +143,16 @@ __global__ __launch_bounds__(256) void rns_split_kernel(SplitJobs jobs, u64 K, u
         u32 wd[4];
 #pragma unroll
         for (u32 d = 0; d < 4; d++) {
-            u32 packed = 0;
+            u32 r[4];
 #pragma unroll
             for (u32 e = 0; e < 4; e++) {
                 const u64 yy = y[4 * d + e];
                 const i32 t = __builtin_amdgcn_sdot4((i32)(u32)(yy >> 32), chi,
                                                      __builtin_amdgcn_sdot4((i32)(u32)yy, clo, 0, false), false);
-                const i32 r = t - (i32)rintf((float)t * w) * m;
-                packed |= ((u32)r & 0xFFu) << (8 * e);
+                r[e] = (u32)(t - (i32)rintf((float)t * w) * m);
             }
-            wd[d] = packed;
+            // the low bytes of the four residues, two byte permutes and an or
+            wd[d] = __builtin_amdgcn_perm(r[1], r[0], 0x0c0c0400u) | __builtin_amdgcn_perm(r[3], r[2], 0x04000c0cu);
         }
         *(uint4 *)(dst + (u64)i * plane_stride) = make_uint4(wd[0], wd[1], wd[2], wd[3]);
     }
