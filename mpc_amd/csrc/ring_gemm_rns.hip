@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void rns_split_kernel(SplitJobs jobs, u64 K, u
             // the low bytes of the four residues, two byte permutes and an or
             wd[d] = __builtin_amdgcn_perm(r[1], r[0], 0x0c0c0400u) | __builtin_amdgcn_perm(r[3], r[2], 0x04000c0cu);
         }
-        *(uint4 *)(dst + (u64)i * plane_stride) = make_uint4(wd[0], wd[1], wd[2], wd[3]);
+        st_stream((uint4 *)(dst + (u64)i * plane_stride), wd[0], wd[1], wd[2], wd[3]);
     }
 }
 
