@@ -107,6 +107,14 @@ def test_ring_gemm_both_formulations(gpu, orc, mode, monkeypatch):
     test_ring_gemm_accumulate_and_mixed_layouts(gpu, orc)
     for r, l, c, lay in ((129, 130, 131, 0), (300, 17, 260, 1), (600, 130, 520, 0), (257, 97, 255, 1)):
         test_ring_gemm_parity(gpu, orc, r, l, c, lay)
+    # the largest integer products one accumulation chunk can hold: K = 8192 words whose eight digits are all -128
+    # (the integer -0x8080808080808080) against themselves and against the all-(+127) word
+    r, l, c = 40, 8192, 33
+    lo, hi = 0x7F7F7F7F7F7F7F80, 0x7F7F7F7F7F7F7F7F
+    for va, vb in ((lo, lo), (lo, hi), (hi, hi)):
+        A = np.full(r * l, va, dtype=np.uint64).view(np.int64)
+        B = np.full(l * c, vb, dtype=np.uint64).view(np.int64)
+        assert np.array_equal(gpu.ring_gemm(A, B, r, l, c), orc.ring_gemm(A, B, r, l, c))
 
 
 def test_relayout(gpu):
