@@ -9,8 +9,9 @@ device buffers handed over by pointer (the messenger round is not part of the ho
 
 --gpus N (launched by torch.distributed.run, one rank per GPU): weak scaling over matmul row-blocks --
 X has 4096*N rows, rank g owns rows [4096 g, 4096 (g+1)), Y is replicated, and the row-blocks of each
-party's Z0 (the message to the previous party) are gathered with one RCCL all-gather per party that stays
-in flight while the following products run and is completed before the timed region ends.  The
+party's Z0 (the message to the previous party) are gathered with one RCCL gather per party to rank 0, the rank that
+faces the messenger (--gather all: an all-gather), which stays in flight while the following products run and is
+completed before the timed region ends.  The
 privateCompare / msb / ReLU items run on per-rank element ranges (n_total, i0, n) and are merged over ranks.
 
 value = ring operations of the reference's formulation (3 products, 2 ops per multiply-add:
@@ -60,10 +61,11 @@ def prof_read(ctx, name):
 
 
 class Aby3MatmulJob:
-    def __init__(self, ctx, torch, dev, n, rank, world, host_gather=False, rows=None, gather=None):
+    def __init__(self, ctx, torch, dev, n, rank, world, host_gather=False, rows=None, gather=None, gather_to="root"):
         self.ctx, self.torch, self.n, self.rank, self.world = ctx, torch, n, rank, world
         self.gather = world > 1 if gather is None else gather  # the collective also runs in a 1-rank process group
         self.host_gather = host_gather
+        self.gather_to = gather_to  # "root": only rank 0 (the rank that faces the messenger) receives; "all": all-gather
         self.rows, self.l, self.c = rows or n, n, n
         self.rows_total = self.rows * world
         self.row0, rows_here = matmul_row_block(self.rows_total, world, rank)
@@ -78,7 +80,8 @@ class Aby3MatmulJob:
         self.RX = [e(self.rows * self.l) for _ in range(3)]
         self.RY = [e(self.l * self.c) for _ in range(3)]
         self.Z0 = [e(self.rows * self.c) for _ in range(3)]
-        self.Zfull = [e(self.rows_total * self.c) for _ in range(3)] if self.gather else None
+        self.Zfull = ([e(self.rows_total * self.c) for _ in range(3)]
+                      if self.gather and (rank == 0 or gather_to == "all") else None)
         self.Zplain = [e(self.rows * self.c) for _ in range(3)]
         self.pending = [None, None, None]  # all-gathers in flight, per party
         # pop-stream checkpoints for everything a step consumes (fresh engines every step)
@@ -106,15 +109,23 @@ class Aby3MatmulJob:
             ctx.call("aby3_matmul_local_rows", self.RX[j], self.RX[nx], self.RY[j], self.RY[nx], self.rows, self.l,
                      self.c, self.row0, sn, pm, sp, pm, self.Z0[j])
             if self.gather:
-                # the message party j hands to the messenger is all row-blocks of its Z0: one all-gather per party,
+                # the message party j hands to the messenger is all row-blocks of its Z0: one gather per party,
                 # started as soon as the block exists.  It travels over xGMI while the following products run -- of
                 # this step and, for the last party, of the next one (the steps are independent jobs); it is waited
                 # for before its source block is overwritten, and drain() completes the last ones.
                 import torch.distributed as dist
+                root = self.gather_to == "root"
                 if self.host_gather:  # rehearsal without RCCL (gloo): through host memory
                     parts = [self.torch.empty(self.Z0[j].numel(), dtype=self.torch.int64) for _ in range(self.world)]
-                    dist.all_gather(parts, self.Z0[j].cpu())
-                    self.Zfull[j].copy_(self.torch.cat(parts))
+                    if root:
+                        dist.gather(self.Z0[j].cpu(), parts if self.rank == 0 else None, dst=0)
+                    else:
+                        dist.all_gather(parts, self.Z0[j].cpu())
+                    if self.Zfull is not None:
+                        self.Zfull[j].copy_(self.torch.cat(parts))
+                elif root:
+                    outs = list(self.Zfull[j].chunk(self.world)) if self.rank == 0 else None
+                    self.pending[j] = dist.gather(self.Z0[j], outs, dst=0, async_op=True)
                 else:
                     self.pending[j] = dist.all_gather_into_tensor(self.Zfull[j], self.Z0[j], async_op=True)
         for j in range(3):
@@ -141,10 +152,21 @@ class Aby3MatmulJob:
         """All parties reveal the same Z, and sampled entries equal the exact big-integer dot products."""
         t = self.torch
         assert t.equal(self.Zplain[0], self.Zplain[1]) and t.equal(self.Zplain[1], self.Zplain[2])
-        if self.gather:  # this rank's block of every gathered message is its own Z0
-            lo = self.row0 * self.c
-            for j in range(3):
-                assert t.equal(self.Zfull[j][lo:lo + self.rows * self.c], self.Z0[j]), "gathered message differs"
+        if self.gather:
+            # every rank's block of every gathered message: its wrap-around sum travels separately and is compared with
+            # the sum of the block that arrived; a rank's own block is compared word for word
+            import torch.distributed as dist
+            mine = [int(self.Z0[j].sum().item()) for j in range(3)]
+            sums = [None] * self.world
+            dist.all_gather_object(sums, mine)
+            if self.Zfull is not None:
+                nb = self.rows * self.c
+                for j in range(3):
+                    lo = self.row0 * self.c
+                    assert t.equal(self.Zfull[j][lo:lo + nb], self.Z0[j]), "gathered message differs"
+                    for g in range(self.world):
+                        assert int(self.Zfull[j][g * nb:(g + 1) * nb].sum().item()) == sums[g][j], \
+                            f"block of rank {g} in the message of party {j} differs"
         X = self.X.view(self.rows, self.l).cpu().numpy().view(np.uint64)
         Y = self.Y.view(self.l, self.c).cpu().numpy().view(np.uint64)
         Z = self.Zplain[0].view(self.rows, self.c).cpu().numpy().view(np.uint64)
@@ -457,6 +479,8 @@ def main():
     ap.add_argument("--bitwise-log2n", type=int, default=24, help="elements of the privateCompare / msb / ReLU runs")
     ap.add_argument("--rows", type=int, default=0, help="rows of X per GPU when different from --size (a row block "
                     "of a larger product, e.g. --size 16384 --rows 2048 = one GPU's share of the 16384^2 configuration)")
+    ap.add_argument("--gather", default="root", choices=["root", "all"],
+                    help="who receives the row blocks of a party's message: the messenger-facing rank 0, or every rank")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearsal of the multi-rank path on fewer GPUs than ranks (gathers through the host)")
     args = ap.parse_args()
@@ -489,7 +513,7 @@ def main():
     ctx.call("set_stream", torch.cuda.current_stream().cuda_stream)
 
     job = Aby3MatmulJob(ctx, torch, dev, args.size, rank, world, host_gather=args.dist_backend == "gloo", rows=args.rows or None,
-                        gather=dist is not None)
+                        gather=dist is not None, gather_to=args.gather)
 
     def barrier():
         if dist is not None:
