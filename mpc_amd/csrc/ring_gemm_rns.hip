@@ -367,7 +367,7 @@ u64 rns_part_chunk_len(int nparts, u64 l) {
 
 } // namespace
 
-// MPCX_GEMM_RNS: 0 = never, 2 = every shape, otherwise (default) products large enough for the 19 tiled passes to
+// MPCX_GEMM_RNS: 0 = never, 2 = every shape, otherwise (default) products large enough for the 18 tiled passes to
 // beat the positional kernel (measured crossover near 3000^3; below it the 256 x 256 tiles and the two extra passes cost
 // more than the saved multiplications).  Read on every call so that one process can exercise both paths.
 bool ring_gemm_use_rns(u64 r, u64 l, u64 c) {
