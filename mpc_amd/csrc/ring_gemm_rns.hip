@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void rns_split_kernel(SplitJobs jobs, u64 K, u
 // or is landing and stage t+2 is being issued.  The XOR swizzle of the 16-byte halves is the positional kernel's.
 __global__ __launch_bounds__(512) void rns_gemm_kernel(const i8 *__restrict__ Apl, const i8 *__restrict__ Bpl,
                                                        u8 *__restrict__ Y, u32 Mp, u32 Np, u32 nkb, u32 tiles_m, u32 tiles_n,
-                                                       RnsTab T) {
+                                                       u32 GM, RnsTab T) {
     __shared__ __attribute__((aligned(1024))) i8 lds[3 * STAGE_BYTES];
     const u32 tid = threadIdx.x, lane = tid & 63;
     const u32 wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -178,7 +178,6 @@ __global__ __launch_bounds__(512) void rns_gemm_kernel(const i8 *__restrict__ Ap
     const u32 bid = blockIdx.x;
     const u32 qq = nwg / 8, rem = nwg % 8, xcd = bid % 8;
     const u32 swz = (xcd < rem ? xcd * (qq + 1) : rem * (qq + 1) + (xcd - rem) * qq) + bid / 8;
-    const u32 GM = 4;
     const u32 per_group = GM * tiles_n;
     const u32 group = swz / per_group, in_group = swz % per_group;
     const u32 first_m = group * GM;
@@ -407,6 +406,7 @@ int ring_gemm_parts_rns(mpcx_ctx *ctx, const GemmPart *parts, int nparts, u64 r,
     const u32 nkb = (u32)(Kp / RK);
     const u64 soA = layA ? 1 : l, skA = layA ? r : 1;
     const u64 soB = layB ? l : 1, skB = layB ? 1 : c;
+    static const u32 gm = getenv("MPCX_RNS_GM") ? (u32)atoi(getenv("MPCX_RNS_GM")) : 4; // tile rows per group (tuning)
     int first = 1;
     for (u64 kb = 0; kb < l; kb += lc) {
         const u64 klen = (l - kb < lc) ? l - kb : lc;
@@ -443,7 +443,7 @@ int ring_gemm_parts_rns(mpcx_ctx *ctx, const GemmPart *parts, int nparts, u64 r,
         {
             ProfScope ps(ctx, PROF_GEMM);
             hipLaunchKernelGGL(rns_gemm_kernel, dim3(tiles_m * tiles_n, NP), dim3(512), 0, ctx->stream, Apl, Bpl, Y, (u32)Mp,
-                               (u32)Np, nkb, tiles_m, tiles_n, T);
+                               (u32)Np, nkb, tiles_m, tiles_n, gm, T);
         }
         {
             ProfScope ps(ctx, PROF_SPLIT);
