@@ -367,14 +367,15 @@ u64 rns_part_chunk_len(int nparts, u64 l) {
 } // namespace
 
 // MPCX_GEMM_RNS: 0 = never, 2 = every shape, otherwise (default) products large enough for the 18 tiled passes to
-// beat the positional kernel (measured crossover near 3000^3; below it the 256 x 256 tiles and the two extra passes cost
-// more than the saved multiplications).  Read on every call so that one process can exercise both paths.
+// beat the positional kernel: measured on cubes, 2048^3 0.31 against 0.27 ms, 2560^3 0.52 against 0.59, 4096^3 1.44
+// against 1.85, 6144^3 4.2 against 6.0 (below the crossover the 256 x 256 tiles and the two extra passes cost more than
+// the saved multiplications).  Read on every call so that one process can exercise both paths.
 bool ring_gemm_use_rns(u64 r, u64 l, u64 c) {
     const char *e = getenv("MPCX_GEMM_RNS");
     const int mode = e ? atoi(e) : 1;
     if (mode == 0) return false;
     if (mode == 2) return true;
-    return r * c >= 3072ull * 3072ull && l >= 1024;
+    return r * c >= 2560ull * 2560ull && l >= 2048;
 }
 
 u64 ring_gemm_rns_ws_bytes(int nparts, u64 r, u64 l, u64 c) {

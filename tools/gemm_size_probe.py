@@ -13,7 +13,7 @@ ctx = Context(0)
 ctx.call("set_stream", torch.cuda.current_stream().cuda_stream)
 g = torch.Generator(device=dev)
 g.manual_seed(1)
-for n in (128, 256, 512, 768, 1024, 1536, 2048, 4096):
+for n in [int(v) for v in os.environ.get("PROBE_SIZES", "128,256,512,768,1024,1536,2048,4096").split(",")]:
     A = torch.randint(-2 ** 63, 2 ** 63 - 1, (n * n,), dtype=torch.int64, device=dev, generator=g)
     B = torch.randint(-2 ** 63, 2 ** 63 - 1, (n * n,), dtype=torch.int64, device=dev, generator=g)
     Z = torch.empty(n * n, dtype=torch.int64, device=dev)
