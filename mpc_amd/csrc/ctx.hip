@@ -87,6 +87,7 @@ int mpcx_shutdown(mpcx_ctx *ctx) {
 const char *mpcx_last_error(mpcx_ctx *ctx) { return ctx ? ctx->err.c_str() : g_init_err.c_str(); }
 
 int mpcx_set_stream(mpcx_ctx *ctx, void *hip_stream) {
+    MPCX_REQUIRE(ctx, "mpcx_set_stream: the context is NULL (already shut down?)");
     // work queued on the old stream may still use the workspace, cached slices and recycled blocks
     MPCX_HIP(hipStreamSynchronize(ctx->stream));
     if (ctx->own_stream && ctx->stream) MPCX_HIP(hipStreamDestroy(ctx->stream));
@@ -94,9 +95,10 @@ int mpcx_set_stream(mpcx_ctx *ctx, void *hip_stream) {
     ctx->own_stream = false;
     return 0;
 }
-void *mpcx_get_stream(mpcx_ctx *ctx) { return (void *)ctx->stream; }
+void *mpcx_get_stream(mpcx_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 
 int mpcx_sync(mpcx_ctx *ctx) {
+    MPCX_REQUIRE(ctx, "mpcx_sync: the context is NULL (already shut down?)");
     MPCX_HIP(hipStreamSynchronize(ctx->stream));
     return 0;
 }
@@ -109,6 +111,7 @@ static int pool_drain(mpcx_ctx *ctx) {
     return 0;
 }
 int mpcx_malloc(mpcx_ctx *ctx, uint64_t bytes, void **out) {
+    MPCX_REQUIRE(ctx, "mpcx_malloc: the context is NULL (already shut down?)");
     MPCX_REQUIRE(out, "mpcx_malloc: out is NULL");
     const u64 want = ((bytes ? bytes : 8) + 255) & ~255ull;
     // smallest idle block that fits and wastes at most a quarter
@@ -131,6 +134,7 @@ int mpcx_malloc(mpcx_ctx *ctx, uint64_t bytes, void **out) {
     return 0;
 }
 int mpcx_free(mpcx_ctx *ctx, void *p) {
+    MPCX_REQUIRE(ctx, "mpcx_free: the context is NULL (already shut down?)");
     if (!p) return 0;
     auto it = ctx->pool_live.find(p);
     MPCX_REQUIRE(it != ctx->pool_live.end(), "mpcx_free: %p was not allocated by mpcx_malloc on this context", p);
@@ -146,23 +150,27 @@ int mpcx_free(mpcx_ctx *ctx, void *p) {
     return 0;
 }
 int mpcx_set_pool_limit(mpcx_ctx *ctx, uint64_t max_idle_bytes) {
+    MPCX_REQUIRE(ctx, "mpcx_set_pool_limit: the context is NULL (already shut down?)");
     ctx->pool_cap = max_idle_bytes;
     if (ctx->pool_idle_bytes > max_idle_bytes) return pool_drain(ctx);
     return 0;
 }
 int mpcx_h2d(mpcx_ctx *ctx, void *dst, const void *src, uint64_t bytes) {
+    MPCX_REQUIRE(ctx, "mpcx_h2d: the context is NULL (already shut down?)");
     if (!bytes) return 0;
     MPCX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
     MPCX_HIP(hipStreamSynchronize(ctx->stream)); // the host buffer may be pageable and reused at once
     return 0;
 }
 int mpcx_d2h(mpcx_ctx *ctx, void *dst, const void *src, uint64_t bytes) {
+    MPCX_REQUIRE(ctx, "mpcx_d2h: the context is NULL (already shut down?)");
     if (!bytes) return 0;
     MPCX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     MPCX_HIP(hipStreamSynchronize(ctx->stream));
     return 0;
 }
 int mpcx_d2d(mpcx_ctx *ctx, void *dst, const void *src, uint64_t bytes) {
+    MPCX_REQUIRE(ctx, "mpcx_d2d: the context is NULL (already shut down?)");
     if (!bytes) return 0;
     MPCX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
     return 0;
@@ -170,6 +178,7 @@ int mpcx_d2d(mpcx_ctx *ctx, void *dst, const void *src, uint64_t bytes) {
 static const char *kProfNames[PROF_SLOTS] = {"limb_gemm", "split_limbs", "prg_fill", "pc_party", "pc_helper", "msb_round"};
 
 int mpcx_profile(mpcx_ctx *ctx, int enable) {
+    MPCX_REQUIRE(ctx, "mpcx_profile: the context is NULL (already shut down?)");
     MPCX_HIP(hipStreamSynchronize(ctx->stream));
     for (auto &v : ctx->prof_ev) {
         for (auto &p : v) {
@@ -182,6 +191,7 @@ int mpcx_profile(mpcx_ctx *ctx, int enable) {
     return 0;
 }
 int mpcx_profile_read(mpcx_ctx *ctx, const char *kernel, double *total_ms, uint64_t *launches) {
+    MPCX_REQUIRE(ctx, "mpcx_profile_read: the context is NULL (already shut down?)");
     MPCX_REQUIRE(kernel && total_ms && launches, "mpcx_profile_read: NULL pointer");
     MPCX_HIP(hipStreamSynchronize(ctx->stream));
     for (int s = 0; s < PROF_SLOTS; s++) {
@@ -200,6 +210,7 @@ int mpcx_profile_read(mpcx_ctx *ctx, const char *kernel, double *total_ms, uint6
 }
 
 int mpcx_reserve_workspace(mpcx_ctx *ctx, uint64_t bytes) {
+    MPCX_REQUIRE(ctx, "mpcx_reserve_workspace: the context is NULL (already shut down?)");
     void *p;
     return mpcx_ws(ctx, bytes, &p);
 }

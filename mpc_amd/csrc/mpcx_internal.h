@@ -164,8 +164,9 @@ int ring_gemm_parts(mpcx_ctx *ctx, const GemmPart *parts, int nparts, u64 r, u64
 // workspace bytes ring_gemm_parts takes from the front of the context workspace (a caller may reserve
 // more and use the tail for itself)
 u64 ring_gemm_ws_bytes(int nparts, u64 r, u64 l, u64 c);
-// the same product through a residue number system (ring_gemm_rns.hip): 19 plain int8 products instead of 36
+// the same product through a residue number system (ring_gemm_rns.hip): 18 plain int8 products instead of 36
 bool ring_gemm_use_rns(u64 r, u64 l, u64 c);
+u32 gemm_group_rows(const char *env_name, u32 tiles_m);
 u64 ring_gemm_rns_ws_bytes(int nparts, u64 r, u64 l, u64 c);
 int ring_gemm_parts_rns(mpcx_ctx *ctx, const GemmPart *parts, int nparts, u64 r, u64 l, u64 c, int layA, int layB,
                         const i64 *add, const i64 *sub, i64 *Z, int layZ, int accumulate);

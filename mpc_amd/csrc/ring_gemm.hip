@@ -119,7 +119,8 @@ __global__ __launch_bounds__(256) void split_limbs_kernel(SplitJobs jobs, u64 K,
 // both A and B, so every k meets its partner exactly once whatever the hardware's internal k order.
 // Accumulator map (all gfx950 32x32 MFMAs): col = l & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(l >> 5).
 //
-// ABL (development ablation, 0 in production): 1 = no MFMA / fragment reads, 2 = no operand staging.
+// ABL is 0 in every production build.  A build with -DMPCX_DEV_PROBES also instantiates the timing ablations
+// 1 = no MFMA / fragment reads, 2 = no operand staging (their results are garbage).
 template <int ABL>
 __global__ __launch_bounds__(512) void limb_gemm_kernel(const i8 *__restrict__ Apl, const i8 *__restrict__ Bpl,
                                                         u64 *__restrict__ Z, u32 M, u32 N, u64 ldz_row, u64 ldz_col,
@@ -307,6 +308,7 @@ __global__ __launch_bounds__(512) void limb_gemm_kernel(const i8 *__restrict__ A
 }
 
 
+#ifdef MPCX_DEV_PROBES
 // Development probe (MPCX_GEMM_ABLATE=3, results are garbage): the MFMA stream of limb_gemm_kernel re-expressed
 // with v_mfma_i32_16x16x64_i8 (four per 32x32 tile and 64 bytes of K), fragments read from LDS, nothing staged.
 // Only its run time and the clock the chip holds are of interest.
@@ -346,6 +348,7 @@ __global__ __launch_bounds__(512) void limb_gemm_shape_probe(i32 *__restrict__ C
         for (int t = 0; t < 4; t++) sum += acc[s][t];
     *(v4i *)out = sum;
 }
+#endif // MPCX_DEV_PROBES
 
 // ---------------------------------------------------------------- relayout
 __global__ __launch_bounds__(256) void relayout_kernel(const u64 *__restrict__ src, u64 *__restrict__ dst, u64 rows,
@@ -368,6 +371,16 @@ __global__ __launch_bounds__(256) void relayout_kernel(const u64 *__restrict__ s
 inline u64 round_up(u64 a, u64 b) { return ceil_div(a, b) * b; }
 
 } // namespace
+
+// Tile rows per group of the XCD-aware tile order (a tuning knob read from the environment, default 4), always
+// within [1, tiles_m]: the kernels divide by it.
+u32 gemm_group_rows(const char *env_name, u32 tiles_m) {
+    const char *e = getenv(env_name);
+    long v = e ? atol(e) : 4;
+    if (v < 1) v = 1;
+    if (v > (long)tiles_m) v = (long)tiles_m;
+    return (u32)v;
+}
 
 // K chunking: per accumulation chunk (all parts concatenated) 8 * Kc * 2^14 must stay below 2^31
 static u64 part_chunk_len(int nparts, u64 l) {
@@ -408,8 +421,10 @@ int ring_gemm_parts(mpcx_ctx *ctx, const GemmPart *parts, int nparts, u64 r, u64
     const u32 nkb = (u32)(Kp / RK);
     const u64 soA = layA ? 1 : l, skA = layA ? r : 1; // A(o=row, k)
     const u64 soB = layB ? l : 1, skB = layB ? 1 : c; // B(o=col, k)
+#ifdef MPCX_DEV_PROBES
     static const int abl = getenv("MPCX_GEMM_ABLATE") ? atoi(getenv("MPCX_GEMM_ABLATE")) : 0;
-    static const u32 gm = getenv("MPCX_GEMM_GM") ? (u32)atoi(getenv("MPCX_GEMM_GM")) : 4;
+#endif
+    const u32 gm = gemm_group_rows("MPCX_GEMM_GM", tiles_m);
     int first = 1;
     for (u64 kb = 0; kb < l; kb += lc) {
         const u64 klen = (l - kb < lc) ? l - kb : lc;
@@ -448,6 +463,7 @@ int ring_gemm_parts(mpcx_ctx *ctx, const GemmPart *parts, int nparts, u64 r, u64
             const u64 ldr = layZ ? (u64)1 : c, ldc = layZ ? r : (u64)1;
             const int acc = (accumulate || !first) ? 1 : 0;
 #define MPCX_GEMM_ARGS Apl, Bpl, (u64 *)Z, (u32)r, (u32)c, ldr, ldc, ad, sb, acc, (u32)Mp, (u32)Np, nkb, tiles_m, tiles_n, gm
+#ifdef MPCX_DEV_PROBES
             if (abl == 3) // timing probe only: scribbles over Z
                 hipLaunchKernelGGL(limb_gemm_shape_probe, grid, block, 0, ctx->stream, (i32 *)Z, (u32)r, (u32)c, nkb);
             else if (abl == 1)
@@ -455,6 +471,7 @@ int ring_gemm_parts(mpcx_ctx *ctx, const GemmPart *parts, int nparts, u64 r, u64
             else if (abl == 2)
                 hipLaunchKernelGGL(limb_gemm_kernel<2>, grid, block, 0, ctx->stream, MPCX_GEMM_ARGS);
             else
+#endif
                 hipLaunchKernelGGL(limb_gemm_kernel<0>, grid, block, 0, ctx->stream, MPCX_GEMM_ARGS);
 #undef MPCX_GEMM_ARGS
         }

@@ -407,7 +407,7 @@ int ring_gemm_parts_rns(mpcx_ctx *ctx, const GemmPart *parts, int nparts, u64 r,
     const u32 nkb = (u32)(Kp / RK);
     const u64 soA = layA ? 1 : l, skA = layA ? r : 1;
     const u64 soB = layB ? l : 1, skB = layB ? 1 : c;
-    static const u32 gm = getenv("MPCX_RNS_GM") ? (u32)atoi(getenv("MPCX_RNS_GM")) : 4; // tile rows per group (tuning)
+    const u32 gm = gemm_group_rows("MPCX_RNS_GM", tiles_m); // tile rows per group (tuning)
     int first = 1;
     for (u64 kb = 0; kb < l; kb += lc) {
         const u64 klen = (l - kb < lc) ? l - kb : lc;

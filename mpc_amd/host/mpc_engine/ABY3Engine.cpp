@@ -89,7 +89,7 @@ void ABY3Engine::reveal(const array<VecI64, 2> &Xj, VecI64 &X_plain) {
     message_send[pe.prev].clear();
     vecI642string(Xj[0], message_send[pe.next]);
     messenger->send_and_recv(message_send, message_recv);
-    assert(message_recv[pe.prev].size() == n * sizeof(int64_t));
+    MSG_CHECK(message_recv[pe.prev].size() == n * sizeof(int64_t));
     Dev<int64_t> a(gpu, n), b(gpu, Xj[0].data(), n), c(gpu, Xj[1].data(), n), out(gpu, n);
     upload_string(a, message_recv[pe.prev]);
     GPU_OK(gpu, mpcx_aby3_reveal3(gpu, a, b, c, out, n));
@@ -104,7 +104,7 @@ void ABY3Engine::reveal_matrix(const array<MatrixXl, 2> &Xj, MatrixXl &X_plain) 
     message_send[pe.prev].clear();
     matrix2string(Xj[0], message_send[pe.next]);
     messenger->send_and_recv(message_send, message_recv);
-    assert(message_recv[pe.prev].size() == n * sizeof(int64_t));
+    MSG_CHECK(message_recv[pe.prev].size() == n * sizeof(int64_t));
     string other;
     matrix2string(Xj[1], other);
     Dev<int64_t> a(gpu, n), b(gpu, n), c(gpu, n), out(gpu, n);
@@ -123,7 +123,7 @@ void ABY3Engine::reveal_bools(const array<vecbool, 2> &Xj, vecbool &X_plain) {
     message_send[pe.prev].clear();
     vecbool2string(Xj[0], message_send[pe.next]);
     messenger->send_and_recv(message_send, message_recv);
-    assert(message_recv[pe.prev].size() == n);
+    MSG_CHECK(message_recv[pe.prev].size() == n);
     Dev<int8_t> a(gpu, n), b(gpu, Xj[0].data(), n), c(gpu, Xj[1].data(), n), out(gpu, n);
     upload_string(a, message_recv[pe.prev]);
     GPU_OK(gpu, mpcx_aby3_reveal3_bools(gpu, a, b, c, out, n));
@@ -137,7 +137,7 @@ void ABY3Engine::reveal_bits(const array<VecI64, 2> &Xj, VecI64 &X_plain) {
     message_send[pe.prev].clear();
     vecI642string(Xj[0], message_send[pe.next]);
     messenger->send_and_recv(message_send, message_recv);
-    assert(message_recv[pe.prev].size() == n * sizeof(int64_t));
+    MSG_CHECK(message_recv[pe.prev].size() == n * sizeof(int64_t));
     Dev<int64_t> a(gpu, n), b(gpu, Xj[0].data(), n), c(gpu, Xj[1].data(), n), out(gpu, n);
     upload_string(a, message_recv[pe.prev]);
     GPU_OK(gpu, mpcx_aby3_reveal3_bits(gpu, a, b, c, out, n));
@@ -237,7 +237,7 @@ void ABY3Engine::add_prepare(const array<VecI64, 2> &Xj, array<VecI64, 2> &Gj, a
     message_send[pe.next].clear();
     c0.to_string(message_send[pe.prev]);
     messenger->send_and_recv(message_send, message_recv);
-    assert(message_recv[pe.next].size() == n * sizeof(int64_t));
+    MSG_CHECK(message_recv[pe.next].size() == n * sizeof(int64_t));
     upload_string(c1, message_recv[pe.next]);
     Dev<int64_t> p0(gpu, n), p1(gpu, n), g0(gpu, n);
     GPU_OK(gpu, mpcx_aby3_add_prepare_step2(gpu, x0, x1, c0, c1, n, p0, p1, g0));
@@ -278,7 +278,7 @@ void ABY3Engine::msb(const array<VecI64, 2> &Gj, const array<VecI64, 2> &Pj, arr
         message_send[pe.prev].resize(bytes);
         if (bytes) msg.down(&message_send[pe.prev][0], bytes);
         messenger->send_and_recv(message_send, message_recv);
-        assert(message_recv[pe.next].size() == bytes);
+        MSG_CHECK(message_recv[pe.next].size() == bytes);
         upload_string(msg, message_recv[pe.next]);
         GPU_OK(gpu, mpcx_aby3_msb_round_post(gpu, state, n, temp, msg));
     }
@@ -335,7 +335,7 @@ void ABY3Engine::bit_inject(const array<VecI64, 2> &Aj, const array<vecbool, 2> 
         to1.to_string(message_send[1]);
         to2.to_string(message_send[2]);
         messenger->send_and_recv(message_send, message_recv);
-        assert(message_recv[1].size() == 2 * w && message_recv[2].size() == w);
+        MSG_CHECK(message_recv[1].size() == 2 * w && message_recv[2].size() == w);
         upload_string(from1, message_recv[1]);
         upload_string(from2, message_recv[2]);
         GPU_OK(gpu, mpcx_aby3_bit_inject_p0_post(gpu, b0, n, 0, n, s01.init_seed, pop01, s20.init_seed, pop20, from1, from2, c0, c1));
@@ -349,7 +349,7 @@ void ABY3Engine::bit_inject(const array<VecI64, 2> &Aj, const array<vecbool, 2> 
         to0.to_string(message_send[0]);
         to2.to_string(message_send[2]);
         messenger->send_and_recv(message_send, message_recv);
-        assert(message_recv[0].size() == 2 * w && message_recv[2].size() == w);
+        MSG_CHECK(message_recv[0].size() == 2 * w && message_recv[2].size() == w);
         upload_string(from0, message_recv[0]);
         upload_string(from2, message_recv[2]);
         GPU_OK(gpu, mpcx_aby3_bit_inject_p1_post(gpu, b1, n, 0, n, s01.init_seed, pop01, s12.init_seed, pop12, from0, from2, c0, c1));
@@ -363,7 +363,7 @@ void ABY3Engine::bit_inject(const array<VecI64, 2> &Aj, const array<vecbool, 2> 
         to0.to_string(message_send[0]);
         to1.to_string(message_send[1]);
         messenger->send_and_recv(message_send, message_recv);
-        assert(message_recv[0].size() == 3 * w && message_recv[1].size() == 3 * w);
+        MSG_CHECK(message_recv[0].size() == 3 * w && message_recv[1].size() == 3 * w);
         upload_string(from0, message_recv[0]);
         upload_string(from1, message_recv[1]);
         GPU_OK(gpu, mpcx_aby3_bit_inject_p2_post(gpu, b0, b1, n, 0, n, s20.init_seed, pop20, s12.init_seed, pop12, from0, from1, c0, c1));

@@ -64,11 +64,11 @@ void MyEngine::reveal(const VecI64 &Xj, VecI64 &X_plain) {
     messenger->send_and_recv(message_send, message_recv);
     Dev<int64_t> u(gpu, n), v(gpu, n), out(gpu, n);
     if (party_id == 2) {
-        assert(message_recv[0].size() == n * W && message_recv[1].size() == n * W);
+        MSG_CHECK(message_recv[0].size() == n * W && message_recv[1].size() == n * W);
         upload_string(u, message_recv[0]);
         upload_string(v, message_recv[1]);
     } else {
-        assert(message_recv[1 - party_id].size() == n * W);
+        MSG_CHECK(message_recv[1 - party_id].size() == n * W);
         upload_string(u, message_recv[1 - party_id]);
         v.up(Xj.data(), n);
     }
@@ -114,11 +114,11 @@ void MyEngine::reveal_vec_bools(const vecbool &Xj, vecbool &X_plain) {
     messenger->send_and_recv(message_send, message_recv);
     Dev<int8_t> u(gpu, n), v(gpu, n), out(gpu, n);
     if (party_id == 2) {
-        assert(message_recv[0].size() == n && message_recv[1].size() == n);
+        MSG_CHECK(message_recv[0].size() == n && message_recv[1].size() == n);
         upload_string(u, message_recv[0]);
         upload_string(v, message_recv[1]);
     } else {
-        assert(message_recv[1 - party_id].size() == n);
+        MSG_CHECK(message_recv[1 - party_id].size() == n);
         upload_string(u, message_recv[1 - party_id]);
         v.up(Xj.data(), n);
     }
@@ -139,11 +139,11 @@ void MyEngine::reveal_L_1(const VecI64 &Xj, VecI64 &X_plain) {
     messenger->send_and_recv(message_send, message_recv);
     Dev<int64_t> u(gpu, n), v(gpu, n), out(gpu, n);
     if (party_id == 2) {
-        assert(message_recv[0].size() == n * W && message_recv[1].size() == n * W);
+        MSG_CHECK(message_recv[0].size() == n * W && message_recv[1].size() == n * W);
         upload_string(u, message_recv[0]);
         upload_string(v, message_recv[1]);
     } else {
-        assert(message_recv[1 - party_id].size() == n * W);
+        MSG_CHECK(message_recv[1 - party_id].size() == n * W);
         upload_string(u, message_recv[1 - party_id]);
         v.up(Xj.data(), n);
     }
@@ -164,11 +164,11 @@ void MyEngine::reveal_zp(const vector<zpshare> &Xbits_j, vector<zpshare> &Xbits_
     messenger->send_and_recv(message_send, message_recv);
     Dev<uint16_t> u(gpu, 64 * n), v(gpu, 64 * n), out(gpu, 64 * n);
     if (party_id == 2) {
-        assert(message_recv[0].size() == n * ZP && message_recv[1].size() == n * ZP);
+        MSG_CHECK(message_recv[0].size() == n * ZP && message_recv[1].size() == n * ZP);
         upload_string(u, message_recv[0]);
         upload_string(v, message_recv[1]);
     } else {
-        assert(message_recv[1 - party_id].size() == n * ZP);
+        MSG_CHECK(message_recv[1 - party_id].size() == n * ZP);
         upload_string(u, message_recv[1 - party_id]);
         v.up(Xbits_j.data(), 64 * n);
     }
@@ -210,7 +210,7 @@ void MyEngine::matrix_mul(const MatrixXl &Xj, const MatrixXl &Yj, MatrixXl &Zj) 
     ef.to_string(message_send[peer]);
     message_send[2].clear();
     messenger->send_and_recv(message_send, message_recv);
-    assert(message_recv[2].size() == nc * W && message_recv[peer].size() == (na + nb) * W);
+    MSG_CHECK(message_recv[2].size() == nc * W && message_recv[peer].size() == (na + nb) * W);
     upload_string(c, message_recv[2]);
     upload_string(ef_peer, message_recv[peer]);
     GPU_OK(gpu, mpcx_my_beaver_party_finish_matmul(gpu, (int)party_id, s2, c, ef, ef_peer, rows, lens, cols, 1, z));
@@ -249,7 +249,7 @@ void MyEngine::vector_mul(const VecI64 &Xj, const VecI64 &Yj, VecI64 &Zj) {
     ef.to_string(message_send[peer]);
     message_send[2].clear();
     messenger->send_and_recv(message_send, message_recv);
-    assert(message_recv[2].size() == n * W && message_recv[peer].size() == 2 * n * W);
+    MSG_CHECK(message_recv[2].size() == n * W && message_recv[peer].size() == 2 * n * W);
     upload_string(c, message_recv[2]);
     upload_string(ef_peer, message_recv[peer]);
     GPU_OK(gpu, mpcx_my_beaver_party_finish_vecmul(gpu, (int)party_id, s2, c, ef, ef_peer, n, 0, n, z));
@@ -275,7 +275,7 @@ void MyEngine::privateCompare(const vector<zpshare> &Xbits_j, const vecbool &Bet
     message_send[0].clear();
     message_send[1].clear();
     messenger->send_and_recv(message_send, message_recv);
-    assert(message_recv[0].size() == n * ZP && message_recv[1].size() == n * ZP);
+    MSG_CHECK(message_recv[0].size() == n * ZP && message_recv[1].size() == n * ZP);
     Dev<uint16_t> d0(gpu, 64 * n), d1(gpu, 64 * n);
     Dev<int8_t> b(gpu, n);
     upload_string(d0, message_recv[0]);
@@ -315,7 +315,7 @@ void MyEngine::msb(const VecI64 &Aj, vecbool &Bj) {
         message_send[0].clear();
         message_send[1].clear();
         messenger->send_and_recv(message_send, message_recv); // round 2: privateCompare as the helper
-        assert(message_recv[0].size() == n * ZP && message_recv[1].size() == n * ZP);
+        MSG_CHECK(message_recv[0].size() == n * ZP && message_recv[1].size() == n * ZP);
         Dev<uint16_t> d0(gpu, 64 * n), d1(gpu, 64 * n);
         Dev<int8_t> beta1(gpu, n), b0(gpu, n), b1(gpu, n);
         upload_string(d0, message_recv[0]);
@@ -337,7 +337,7 @@ void MyEngine::msb(const VecI64 &Aj, vecbool &Bj) {
     message_send[2].clear();
     rj.to_string(message_send[peer]);
     messenger->send_and_recv(message_send, message_recv); // round 1
-    assert(message_recv[peer].size() == n * W && message_recv[2].size() == n + n * ZP);
+    MSG_CHECK(message_recv[peer].size() == n * W && message_recv[2].size() == n + n * ZP);
     upload_string(rpeer, message_recv[peer]);
     Dev<int8_t> beta0(gpu, n), xlsb(gpu, n), beta1(gpu, n), out(gpu, n);
     Dev<uint16_t> xbits(gpu, 64 * n), d(gpu, 64 * n);
@@ -351,7 +351,7 @@ void MyEngine::msb(const VecI64 &Aj, vecbool &Bj) {
     message_send[2].clear();
     message_send[peer].clear();
     messenger->send_and_recv(message_send, message_recv); // round 3: share of beta'
-    assert(message_recv[2].size() == n);
+    MSG_CHECK(message_recv[2].size() == n);
     upload_string(beta1, message_recv[2]);
     GPU_OK(gpu, mpcx_my_msb_party_finish(gpu, (int)party_id, beta1, beta0, xlsb, R, n, out));
     out.down(Bj.data(), n);
@@ -398,7 +398,7 @@ void MyEngine::bit_inject(const VecI64 &Xj, const vecbool &Aj, VecI64 &Zj) {
     }
     message_send[2].clear();
     messenger->send_and_recv(message_send, message_recv);
-    assert(message_recv[peer].size() == n * W + n && message_recv[2].size() == 4 * n * W);
+    MSG_CHECK(message_recv[peer].size() == n * W + n && message_recv[2].size() == 4 * n * W);
     upload_string(ypeer, message_recv[peer], 0, n * W);
     upload_string(cpeer, message_recv[peer], n * W, n);
     upload_string(deal, message_recv[2]);

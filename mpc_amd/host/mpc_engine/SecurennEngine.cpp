@@ -53,7 +53,7 @@ void SecurennEngine::matrix_mul(const MatrixXl &Xj, const MatrixXl &Yj, MatrixXl
     const size_t peer = 1 - party_id;
     for (auto &m : message_send) m.clear();
     messenger->send_and_recv(message_send, message_recv); // round 1
-    assert(message_recv[2].size() == (na + nb + nc) * W);
+    MSG_CHECK(message_recv[2].size() == (na + nb + nc) * W);
     Dev<int64_t> triple(gpu, na + nb + nc), ef(gpu, na + nb), ef_peer(gpu, na + nb);
     upload_string(triple, message_recv[2]);
     {
@@ -63,7 +63,7 @@ void SecurennEngine::matrix_mul(const MatrixXl &Xj, const MatrixXl &Yj, MatrixXl
     ef.to_string(message_send[peer]);
     message_send[2].clear();
     messenger->send_and_recv(message_send, message_recv); // round 2
-    assert(message_recv[peer].size() == (na + nb) * W);
+    MSG_CHECK(message_recv[peer].size() == (na + nb) * W);
     upload_string(ef_peer, message_recv[peer]);
     Dev<int64_t> z(gpu, nc);
     GPU_OK(gpu, mpcx_snn_beaver_party_finish_matmul(gpu, (int)party_id, triple, ef, ef_peer, rows, lens, cols, 1, z));
@@ -99,7 +99,7 @@ void SecurennEngine::vector_mul(const vector<int64_t> &Xj, const vector<int64_t>
     const size_t peer = 1 - party_id;
     for (auto &m : message_send) m.clear();
     messenger->send_and_recv(message_send, message_recv); // round 1
-    assert(message_recv[2].size() == 3 * n * W);
+    MSG_CHECK(message_recv[2].size() == 3 * n * W);
     Dev<int64_t> t(gpu, 3 * n), ef(gpu, 2 * n), efp(gpu, 2 * n), z(gpu, n);
     upload_string(t, message_recv[2]);
     {
@@ -109,7 +109,7 @@ void SecurennEngine::vector_mul(const vector<int64_t> &Xj, const vector<int64_t>
     ef.to_string(message_send[peer]);
     message_send[2].clear();
     messenger->send_and_recv(message_send, message_recv); // round 2
-    assert(message_recv[peer].size() == 2 * n * W);
+    MSG_CHECK(message_recv[peer].size() == 2 * n * W);
     upload_string(efp, message_recv[peer]);
     GPU_OK(gpu, mpcx_snn_beaver_party_finish_vecmul(gpu, (int)party_id, t.p, t.p + n, t.p + 2 * n, ef.p, ef.p + n,
                                                     efp.p, efp.p + n, n, z));
@@ -142,10 +142,10 @@ void SecurennEngine::reveal(const vector<int64_t> &Xj, vector<int64_t> &X_plain)
     }
     messenger->send_and_recv(message_send, message_recv);
     Dev<int64_t> u(gpu, n), v(gpu, n), out(gpu, n);
-    assert(message_recv[a].size() == n * W);
+    MSG_CHECK(message_recv[a].size() == n * W);
     upload_string(u, message_recv[a]);
     if (party_id == 2) {
-        assert(message_recv[1].size() == n * W);
+        MSG_CHECK(message_recv[1].size() == n * W);
         upload_string(v, message_recv[b]);
     } else {
         v.up(Xj.data(), n);
@@ -213,11 +213,11 @@ void SecurennEngine::reveal_L_1(const vector<int64_t> &Xj, vector<int64_t> &X_pl
     messenger->send_and_recv(message_send, message_recv);
     Dev<int64_t> u(gpu, n), v(gpu, n), out(gpu, n);
     if (party_id == 2) {
-        assert(message_recv[0].size() == n * W && message_recv[1].size() == n * W);
+        MSG_CHECK(message_recv[0].size() == n * W && message_recv[1].size() == n * W);
         upload_string(u, message_recv[0]);
         upload_string(v, message_recv[1]);
     } else {
-        assert(message_recv[1 - party_id].size() == n * W);
+        MSG_CHECK(message_recv[1 - party_id].size() == n * W);
         v.up(Xj.data(), n);
         upload_string(u, message_recv[1 - party_id]);
     }
@@ -239,11 +239,11 @@ void SecurennEngine::reveal_zp(const vector<zpshare> &Xbits_j, vector<zpshare> &
     messenger->send_and_recv(message_send, message_recv);
     Dev<uint16_t> u(gpu, 64 * n), v(gpu, 64 * n), out(gpu, 64 * n);
     if (party_id == 2) {
-        assert(message_recv[0].size() == n * ZP && message_recv[1].size() == n * ZP);
+        MSG_CHECK(message_recv[0].size() == n * ZP && message_recv[1].size() == n * ZP);
         upload_string(u, message_recv[0]);
         upload_string(v, message_recv[1]);
     } else {
-        assert(message_recv[1 - party_id].size() == n * ZP);
+        MSG_CHECK(message_recv[1 - party_id].size() == n * ZP);
         upload_string(u, message_recv[1 - party_id]);
         v.up(Xbits_j.data(), 64 * n);
     }
@@ -269,7 +269,7 @@ void pc_helper_dev(SecurennEngine &e, size_t n, Dev<int8_t> &beta2) {
     e.message_send[0].clear();
     e.message_send[1].clear();
     e.messenger->send_and_recv(e.message_send, e.message_recv);
-    assert(e.message_recv[0].size() == n * ZP && e.message_recv[1].size() == n * ZP);
+    MSG_CHECK(e.message_recv[0].size() == n * ZP && e.message_recv[1].size() == n * ZP);
     Dev<uint16_t> d0(e.gpu, 64 * n), d1(e.gpu, 64 * n);
     upload_string(d0, e.message_recv[0]);
     upload_string(d1, e.message_recv[1]);
@@ -292,14 +292,14 @@ void vecmul_party_dev(SecurennEngine &e, const Dev<int64_t> &x, const Dev<int64_
     const size_t peer = 1 - e.party_id;
     for (auto &m : e.message_send) m.clear();
     e.messenger->send_and_recv(e.message_send, e.message_recv); // round 1
-    assert(e.message_recv[2].size() == 3 * n * W);
+    MSG_CHECK(e.message_recv[2].size() == 3 * n * W);
     Dev<int64_t> t(e.gpu, 3 * n), ef(e.gpu, 2 * n), efp(e.gpu, 2 * n);
     upload_string(t, e.message_recv[2]);
     GPU_OK(e.gpu, mpcx_snn_beaver_party_open_vecmul(e.gpu, x, y, t.p, t.p + n, n, ef.p, ef.p + n));
     ef.to_string(e.message_send[peer]);
     e.message_send[2].clear();
     e.messenger->send_and_recv(e.message_send, e.message_recv); // round 2
-    assert(e.message_recv[peer].size() == 2 * n * W);
+    MSG_CHECK(e.message_recv[peer].size() == 2 * n * W);
     upload_string(efp, e.message_recv[peer]);
     GPU_OK(e.gpu, mpcx_snn_beaver_party_finish_vecmul(e.gpu, (int)e.party_id, t.p, t.p + n, t.p + 2 * n, ef.p, ef.p + n,
                                                       efp.p, efp.p + n, n, z));
@@ -318,7 +318,7 @@ void share_convert_dev(SecurennEngine &e, const Dev<int64_t> *a, size_t n, Dev<i
         e.messenger->send_and_recv(e.message_send, e.message_recv); // round 1
         e.message_send[2].clear();
         e.messenger->send_and_recv(e.message_send, e.message_recv); // round 2: x bits over Z_67 | delta_j
-        assert(e.message_recv[2].size() == n * (ZP + W));
+        MSG_CHECK(e.message_recv[2].size() == n * (ZP + W));
         Dev<uint16_t> xbits(gpu, 64 * n);
         Dev<int64_t> delta(gpu, n), rm1(gpu, n), eta1(gpu, n);
         Dev<int8_t> eta2(gpu, n);
@@ -329,7 +329,7 @@ void share_convert_dev(SecurennEngine &e, const Dev<int64_t> *a, size_t n, Dev<i
         e.message_send[peer].clear();
         e.message_send[2].clear();
         e.messenger->send_and_recv(e.message_send, e.message_recv); // round 4: eta'_j
-        assert(e.message_recv[2].size() == n * W);
+        MSG_CHECK(e.message_recv[2].size() == n * W);
         upload_string(eta1, e.message_recv[2]);
         GPU_OK(gpu, mpcx_snn_sc_party_finish(gpu, (int)e.party_id, *a, delta, eta1, n, 0, n, s01, *y));
         return;
@@ -338,7 +338,7 @@ void share_convert_dev(SecurennEngine &e, const Dev<int64_t> *a, size_t n, Dev<i
     e.message_send[0].clear(); // nothing to say in round 1 (parties 0/1 ignore this slot)
     e.message_send[1].clear();
     e.messenger->send_and_recv(e.message_send, e.message_recv); // round 1
-    assert(e.message_recv[0].size() == n * W && e.message_recv[1].size() == n * W);
+    MSG_CHECK(e.message_recv[0].size() == n * W && e.message_recv[1].size() == n * W);
     {
         Dev<int64_t> x0(gpu, n), x1(gpu, n), d0(gpu, n), d1(gpu, n);
         Dev<uint16_t> xb0(gpu, 64 * n), xb1(gpu, 64 * n);
@@ -400,7 +400,7 @@ void msb_L1_dev(SecurennEngine &e, const Dev<int64_t> *a, size_t n, Dev<int64_t>
     e.message_send[2].clear();
     e.message_send[peer].clear();
     e.messenger->send_and_recv(e.message_send, e.message_recv); // round 1
-    assert(e.message_recv[2].size() == n * (2 * W + ZP));
+    MSG_CHECK(e.message_recv[2].size() == n * (2 * W + ZP));
     Dev<int64_t> xj(gpu, n), xlsb(gpu, n), rj(gpu, n), rpeer(gpu, n), R(gpu, n);
     Dev<uint16_t> xbits(gpu, 64 * n);
     upload_string(xj, e.message_recv[2], 0, n * W);
@@ -409,7 +409,7 @@ void msb_L1_dev(SecurennEngine &e, const Dev<int64_t> *a, size_t n, Dev<int64_t>
     GPU_OK(gpu, mpcx_snn_msbl1_party_open(gpu, *a, xj, n, rj));
     rj.to_string(e.message_send[peer]);
     e.messenger->send_and_recv(e.message_send, e.message_recv); // round 2: open r = 2a + x
-    assert(e.message_recv[peer].size() == n * W);
+    MSG_CHECK(e.message_recv[peer].size() == n * W);
     upload_string(rpeer, e.message_recv[peer]);
     Dev<int8_t> beta0(gpu, n);
     GPU_OK(gpu, mpcx_snn_msbl1_party_pc_inputs(gpu, rj, rpeer, 0, n, s01, beta0, R));
@@ -417,7 +417,7 @@ void msb_L1_dev(SecurennEngine &e, const Dev<int64_t> *a, size_t n, Dev<int64_t>
     e.message_send[2].clear();
     e.message_send[peer].clear();
     e.messenger->send_and_recv(e.message_send, e.message_recv); // round 4: share of beta'
-    assert(e.message_recv[2].size() == n * W);
+    MSG_CHECK(e.message_recv[2].size() == n * W);
     Dev<int64_t> beta1(gpu, n), gamma(gpu, n), delta(gpu, n), theta(gpu, n);
     upload_string(beta1, e.message_recv[2]);
     GPU_OK(gpu, mpcx_snn_msbl1_party_mid(gpu, (int)e.party_id, beta1, xlsb, beta0, R, n, gamma, delta));

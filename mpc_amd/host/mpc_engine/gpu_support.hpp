@@ -18,6 +18,16 @@
         }                                                                              \
     } while (0)
 
+// A received message of the wrong length is a protocol error: checked in every build (an assert would vanish with
+// -DNDEBUG and the upload would then run past the device buffer or the host string).
+#define MSG_CHECK(cond)                                                                          \
+    do {                                                                                         \
+        if (!(cond)) {                                                                           \
+            fprintf(stderr, "%s:%d: unexpected message length: %s\n", __FILE__, __LINE__, #cond); \
+            abort();                                                                             \
+        }                                                                                        \
+    } while (0)
+
 namespace mpcgpu {
 
 #if defined MYDEBUG
@@ -71,7 +81,15 @@ template <class T> class Dev {
 };
 
 template <class T> inline void upload_string(Dev<T> &d, const std::string &s, size_t byte_off = 0, size_t bytes = (size_t)-1) {
+    if (byte_off > s.size() || (bytes != (size_t)-1 && bytes > s.size() - byte_off)) {
+        fprintf(stderr, "upload_string: bytes [%zu, +%zu) outside a message of %zu bytes\n", byte_off, bytes, s.size());
+        abort();
+    }
     if (bytes == (size_t)-1) bytes = s.size() - byte_off;
+    if (bytes > d.n * sizeof(T)) {
+        fprintf(stderr, "upload_string: %zu bytes do not fit a device buffer of %zu bytes\n", bytes, d.n * sizeof(T));
+        abort();
+    }
     if (bytes) GPU_OK(d.ctx, mpcx_h2d(d.ctx, d.p, s.data() + byte_off, bytes));
 }
 

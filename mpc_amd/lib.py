@@ -73,7 +73,8 @@ class DeviceArray:
 
     def free(self):
         if self._own and self.ptr:
-            self.ctx._call("mpcx_free", ctypes.c_void_p(self.ptr))
+            if self.ctx.h:  # a closed context has already released every block it handed out
+                self.ctx._call("mpcx_free", ctypes.c_void_p(self.ptr))
             self.ptr = 0
 
     def __del__(self):
@@ -113,6 +114,8 @@ class Context:
             self.h = None
 
     def _call(self, name, *args):
+        if not self.h:
+            raise MpcxError(f"{name}: the context is closed")
         rc = getattr(self.lib, name)(self.h, *args)
         if rc:
             raise MpcxError(f"{name}: {self.lib.mpcx_last_error(self.h).decode()}")

@@ -12,12 +12,11 @@
 // and not installed in the build image, so the engines cannot be compiled here
 // without writing a stand-in header (not allowed).  This restatement is pinned
 // by (a) the real reference PRgenerator compiled from its own sources into
-// oracle/_ref (PRG words, any seed/length), (b) the known-answer values that the
-// survey session recorded from the compiled reference (PRG states, ABY3 / SecureNN
-// 64x64 matmul share checksums, SecureNN msb n=1000 share checksums), and (c) the
-// algebraic properties the reference's own tests assert.  Segments covered only
-// by (c) -- ABY3 add_prepare / msb / bit_inject share bit patterns -- are
-// "parity unpinned" at the bit-pattern level.
+// oracle/_ref (PRG words and generator state, any seed/length), (b) the PRG
+// known-answer words recorded from the reference, and (c) the algebraic properties
+// the reference's own tests assert (the reference holds no golden vectors of engine
+// shares).  The bit patterns of engine shares are therefore "parity unpinned"
+// against the reference: they are pinned against this restatement only.
 //
 // Every function cites the reference file:line it restates (paths relative to
 // the reference root).
@@ -276,6 +275,11 @@ int orc_aby3_vecmul_local(const i64 *X0, const i64 *X1, const i64 *Y0, const i64
         u64 z = (u64)X0[i] * (u64)Y0[i] + (u64)X0[i] * (u64)Y1[i] + (u64)X1[i] * (u64)Y0[i];
         Z0[i] = (i64)(z + ((u64)a.pop() - (u64)b.pop()));
     }
+    return 0;
+}
+// vecbool_mul local part: ABY3Engine.cpp:253-256 (one byte per boolean, no re-randomisation)
+int orc_aby3_vecbool_mul_local(const i8 *X0, const i8 *X1, const i8 *Y0, const i8 *Y1, u64 n, i8 *Z0) {
+    for (u64 i = 0; i < n; i++) Z0[i] = (i8)((X0[i] & Y0[i]) ^ (X1[i] & Y0[i]) ^ (X0[i] & Y1[i]));
     return 0;
 }
 // reveal / reveal_matrix: ABY3Engine.cpp:142,157 ; reveal_bools :171-174 ; reveal_bits :287-288

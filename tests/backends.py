@@ -95,6 +95,16 @@ class OracleBackend:
         self.o.orc_aby3_reveal3_bools(_c(a, np.int8), _c(b, np.int8), _c(c, np.int8), out, a.size)
         return out
 
+    def aby3_reveal3_bits(self, a, b, c):
+        out = i64(a.size)
+        self.o.orc_aby3_reveal3_bits(_c(a, np.int64), _c(b, np.int64), _c(c, np.int64), out, a.size)
+        return out
+
+    def aby3_vecbool_mul_local(self, X0, X1, Y0, Y1):
+        out = i8(X0.size)
+        self.o.orc_aby3_vecbool_mul_local(_c(X0, np.int8), _c(X1, np.int8), _c(Y0, np.int8), _c(Y1, np.int8), X0.size, out)
+        return out
+
     def aby3_add_prepare_step1(self, X0, X1):
         out = i64(X0.size)
         self.o.orc_aby3_add_prepare_step1(_c(X0, np.int64), _c(X1, np.int64), X0.size, out)
@@ -402,6 +412,14 @@ class GpuBackend:
         return self._go("aby3_reveal3_bools", _c(a, np.int8), _c(b, np.int8), _c(c, np.int8), ("out", np.int8, a.size),
                         a.size)
 
+    def aby3_reveal3_bits(self, a, b, c):
+        return self._go("aby3_reveal3_bits", _c(a, np.int64), _c(b, np.int64), _c(c, np.int64), ("out", np.int64, a.size),
+                        a.size)
+
+    def aby3_vecbool_mul_local(self, X0, X1, Y0, Y1):
+        return self._go("aby3_vecbool_mul_local", _c(X0, np.int8), _c(X1, np.int8), _c(Y0, np.int8), _c(Y1, np.int8),
+                        X0.size, ("out", np.int8, X0.size))
+
     def aby3_add_prepare_step1(self, X0, X1):
         return self._go("aby3_add_prepare_step1", _c(X0, np.int64), _c(X1, np.int64), X0.size,
                         ("out", np.int64, X0.size))
@@ -606,6 +624,15 @@ class ResidentBackend(GpuBackend):
     def down(self, d):
         self.ctx.sync()
         return d.to_host()
+
+    def tensor(self, d):
+        """The device array as a torch tensor on the same memory (no copy, no synchronisation)."""
+        t = d
+        while not hasattr(t, "data_ptr"):
+            t = t._owner
+        off = d.ptr - t.data_ptr()
+        flat = t.view(-1).view(self.torch.uint8)[off:off + d.nbytes]
+        return flat.view(self._tdt[d.dtype])
 
     def _go(self, name, *args):
         dev, outs = [], []

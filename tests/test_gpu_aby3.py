@@ -99,7 +99,7 @@ def test_ring_gemm_random_shapes_and_layouts(gpu, orc):
 
 @pytest.mark.parametrize("mode", ["0", "2"])
 def test_ring_gemm_both_formulations(gpu, orc, mode, monkeypatch):
-    """The positional (36 digit-pair products) and the residue (19 products + CRT) kernels, each forced for every
+    """The positional (36 digit-pair products) and the residue (18 products + CRT) kernels, each forced for every
     shape: random shapes and layouts, extreme digits with two K chunks, accumulation, and the tile-ragged large case."""
     monkeypatch.setenv("MPCX_GEMM_RNS", mode)
     test_ring_gemm_random_shapes_and_layouts(gpu, orc)
@@ -214,6 +214,28 @@ def test_aby3_misc_segments_parity(gpu, orc):
     assert np.array_equal(gpu.ring_sar(a, 16), orc.ring_sar(a, 16))
     assert np.array_equal(gpu.ring_shl1(a), orc.ring_shl1(a))
     assert np.array_equal(gpu.ring_sub(a, b), orc.ring_sub(a, b))
+
+
+@pytest.mark.parametrize("n", [1, 100, 4099, (1 << 18) + 5])
+def test_aby3_vecbool_mul_and_reveal_bits_parity(gpu, orc, n):
+    """vecbool_mul's local product (ABY3Engine.cpp:253-256; n = 100 is test/test_ABY3.cpp:155-180's size) and
+    reveal_bits' xor (:287-288) against the oracle; the three parties' products reveal X & Y."""
+    rng = np.random.default_rng(n)
+    xs = [rng.integers(0, 2, n, dtype=np.int8) for _ in range(3)]
+    ys = [rng.integers(0, 2, n, dtype=np.int8) for _ in range(3)]
+    zs = []
+    for j in range(3):
+        nx = (j + 1) % 3
+        g = gpu.aby3_vecbool_mul_local(xs[j], xs[nx], ys[j], ys[nx])
+        assert np.array_equal(g, orc.aby3_vecbool_mul_local(xs[j], xs[nx], ys[j], ys[nx]))
+        zs.append(g)
+    assert np.array_equal(zs[0] ^ zs[1] ^ zs[2], (xs[0] ^ xs[1] ^ xs[2]) & (ys[0] ^ ys[1] ^ ys[2]))
+    # inputs outside {0, 1}: the reference's int8 & and ^ apply to whole bytes
+    wild = [rng.integers(-128, 128, n, dtype=np.int8) for _ in range(4)]
+    assert np.array_equal(gpu.aby3_vecbool_mul_local(*wild), orc.aby3_vecbool_mul_local(*wild))
+    a, b, c = rnd(rng, n), rnd(rng, n), rnd(rng, n)
+    got = gpu.aby3_reveal3_bits(a, b, c)
+    assert np.array_equal(got, orc.aby3_reveal3_bits(a, b, c)) and np.array_equal(got, a ^ b ^ c)
 
 
 def test_empty_inputs_are_noops(gpu):

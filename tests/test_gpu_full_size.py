@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 pytestmark = [pytest.mark.gpu, pytest.mark.timeout(900)]
 
-KEY01, KEYS = 0xAB01, 0xF0
+KEY01, KEY20, KEYS = 0xAB01, 0xCA20, 0xF0
 
 
 @pytest.fixture(scope="module")
@@ -119,13 +119,14 @@ def test_aby3_relu_chain_2_24(env):
 
 
 def test_aby3_relu_chain_2_28_in_batches(env):
-    """The 2^28-element ReLU chain as sixteen element ranges of 2^24 (n_total, i0, n): every range reveals max(x, 0)
-    although its pop-stream offsets are those of the whole vector (up to 7 * 2^28 words into each stream)."""
+    """The 2^28-element ReLU chain as sixteen element ranges of 2^24 (n_total, i0, n), every one of them: each range
+    reveals max(x, 0) although its pop-stream offsets are those of the whole vector (up to 7 * 2^28 words into each
+    stream), and the replicated shares of neighbouring parties agree."""
     ctx, torch, dev, be = env
     nt, n = 1 << 28, 1 << 24
     x = torch.empty(n, dtype=torch.int64, device=dev)
-    up = lambda d: torch.from_numpy(be.down(d)).to(dev)
-    for b in (0, 7, 15):  # first, middle and last range (each is independent of the others)
+    T = be.tensor
+    for b in range(16):
         i0 = b * n
         ctx.call("prg_fill_pop", 21, 0, i0, n, x)
         w = pr.World(be, record=False, n_total=nt, i0=i0)
@@ -133,16 +134,87 @@ def test_aby3_relu_chain_2_28_in_batches(env):
         Gs, Ps = pr.aby3_add_prepare(w, Xs)
         Zb = pr.aby3_msb(w, Gs, Ps)
         C = pr.aby3_bit_inject(w, Xs, Zb)
-        relu = sum(up(be.ring_sub(Xs[j][0], C[j][0])) for j in range(3))
+        relu = sum(T(be.ring_sub(Xs[j][0], C[j][0])) for j in range(3))
+        torch.cuda.synchronize()
         assert torch.equal(relu, torch.clamp(x, min=0)), f"range {b}"
+        assert torch.equal(T(Zb[0][0]) ^ T(Zb[1][0]) ^ T(Zb[2][0]), (x < 0).to(torch.int8)), f"range {b}: sign bits"
         for j in range(3):
-            assert torch.equal(up(C[j][1]), up(C[(j + 1) % 3][0])), f"range {b}: replicated shares disagree"
+            assert torch.equal(T(C[j][1]), T(C[(j + 1) % 3][0])), f"range {b}: replicated shares disagree"
+        del Xs, Gs, Ps, Zb, C, relu
+
+
+def test_aby3_matmul_config5_row_block(env, monkeypatch):
+    """One GPU's row block of the 16384 x 16384 configuration (rows [12288, 14336) of X, l = c = 16384: four
+    accumulation chunks per product, mask words from offset row0 * c of both pop streams), computed by the digit-pair
+    and by the residue kernels.  The two results are equal word for word; after the mask pop(next) - pop(prev)
+    (ABY3Engine.cpp:190-197) is taken off, the block passes a Freivalds check, 24 entries equal exact big-integer dot
+    products, and one whole row equals X0 (Y0 + Y1) + X1 Y0 (:189) computed with wrapping 64-bit arithmetic."""
+    ctx, torch, dev, _ = env
+    rows, l, c, row0, pm = 2048, 16384, 16384, 6 * 2048, 3 * 16384 * 16384 + 5
+    e = lambda k: torch.empty(k, dtype=torch.int64, device=dev)
+    X0, X1, Y0, Y1 = e(rows * l), e(rows * l), e(l * c), e(l * c)
+    for k, t in enumerate((X0, X1, Y0, Y1)):  # uniform 64-bit words
+        ctx.call("prg_fill_pop", 31 + k, 0, 0, t.numel(), t)
+    Z = {}
+    for mode in ("0", "2"):
+        monkeypatch.setenv("MPCX_GEMM_RNS", mode)
+        Z[mode] = e(rows * c)
+        ctx.call("aby3_matmul_local_rows", X0, X1, Y0, Y1, rows, l, c, row0, KEY01, pm, KEY20, pm, Z[mode])
+    monkeypatch.delenv("MPCX_GEMM_RNS")
+    torch.cuda.synchronize()
+    assert torch.equal(Z["0"], Z["2"]), "digit-pair and residue kernels disagree"
+    ma, mb = e(rows * c), e(rows * c)
+    ctx.call("prg_fill_pop", KEY01, 0, pm + row0 * c, rows * c, ma)
+    ctx.call("prg_fill_pop", KEY20, 0, pm + row0 * c, rows * c, mb)
+    torch.cuda.synchronize()
+    P = (Z["0"] - (ma - mb)).view(rows, c)  # the product without its mask
+    del ma, mb, Z
+    X0m, X1m, Y0m, Ysum = X0.view(rows, l), X1.view(rows, l), Y0.view(l, c), (Y0 + Y1).view(l, c)
+    matvec = lambda M, v: (M * v.unsqueeze(0)).sum(1)  # int64 arithmetic on the device wraps mod 2^64
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    for _ in range(3):
+        v = torch.randint(-2 ** 63, 2 ** 63 - 1, (c,), dtype=torch.int64, device=dev, generator=g) | 1
+        assert torch.equal(matvec(P, v), matvec(X0m, matvec(Ysum, v)) + matvec(X1m, matvec(Y0m, v))), "P v != X0 ((Y0+Y1) v) + X1 (Y0 v)"
+    i = 1357  # one whole row
+    want_row = (X0m[i].unsqueeze(1) * Ysum).sum(0) + (X1m[i].unsqueeze(1) * Y0m).sum(0)
+    assert torch.equal(P[i], want_row), "row of the product differs"
+    rng = np.random.default_rng(9)
+    for _ in range(24):  # exact integers on the host
+        i, k = int(rng.integers(rows)), int(rng.integers(c))
+        x0, x1 = X0m[i].cpu().numpy().view(np.uint64), X1m[i].cpu().numpy().view(np.uint64)
+        ys, y0 = Ysum[:, k].cpu().numpy().view(np.uint64), Y0m[:, k].cpu().numpy().view(np.uint64)
+        want = (sum(int(a) * int(b) for a, b in zip(x0, ys)) + sum(int(a) * int(b) for a, b in zip(x1, y0))) % (1 << 64)
+        assert int(P[i, k].item()) % (1 << 64) == want, f"P[{i},{k}] wrong"
+
+
+def test_ring_gemm_at_the_residue_threshold_vs_oracle(env, orc):
+    """The smallest product for which the library picks the residue kernels by itself (2560 x 2048 . 2048 x 2560),
+    word for word against the CPU oracle (row blocks of the oracle's product on eight host threads)."""
+    from concurrent.futures import ThreadPoolExecutor
+    import mpc_amd
+    ctx, torch, dev, _ = env
+    r, l, c = 2560, 2048, 2560
+    import ctypes
+    nprod = lambda *dims: mpc_amd.load_library().mpcx_ring_gemm_products(*[ctypes.c_uint64(d) for d in dims])
+    assert nprod(r, l, c) == 18 and nprod(r, l - 1, c) == 36
+    rng = np.random.default_rng(2560)
+    A = rng.integers(-2 ** 63, 2 ** 63, (r, l), dtype=np.int64)
+    B = rng.integers(-2 ** 63, 2 ** 63, (l, c), dtype=np.int64)
+    dA, dB = torch.from_numpy(A).to(dev), torch.from_numpy(B).to(dev)
+    dZ = torch.empty(r * c, dtype=torch.int64, device=dev)
+    ctx.call("ring_gemm_u64", dA, dB, dZ, r, l, c, 0, 0, 0, 0)
+    torch.cuda.synchronize()
+    blk = r // 8
+    with ThreadPoolExecutor(8) as ex:
+        parts = list(ex.map(lambda b: orc.ring_gemm(A[b * blk:(b + 1) * blk].ravel(), B.ravel(), blk, l, c), range(8)))
+    assert np.array_equal(dZ.cpu().numpy(), np.concatenate(parts))
 
 
 @pytest.mark.parametrize("lay,mode", [(0, "0"), (1, "0"), (0, "2"), (1, "2")])
 def test_ring_gemm_ragged_large(env, lay, mode, monkeypatch):
-    """A 3001 x 5003 . 5003 x 2005 ring product (no dimension a multiple of the tile sizes; two K chunks when the parts
-    are concatenated), in both layouts and accumulating onto a previous result: Z v = C v + A (B v) over Z_2^64."""
+    """A 3001 x 5003 . 5003 x 2005 ring product (no dimension a multiple of the tile sizes; one accumulation chunk), in
+    both layouts and accumulating onto a previous result: Z v = C v + A (B v) over Z_2^64."""
     monkeypatch.setenv("MPCX_GEMM_RNS", mode)  # "0": digit-pair kernel, "2": residue kernel
     ctx, torch, dev, _ = env
     r, l, c = 3001, 5003, 2005
