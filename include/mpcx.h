@@ -87,6 +87,16 @@ int mpcx_ring_gemm_u64(mpcx_ctx *ctx, const int64_t *A, const int64_t *B, int64_
  * positional form) or 18 (residues modulo 18 coprime moduli + CRT), chosen by size; MPCX_GEMM_RNS=0 / 2 in the
  * environment forces the first / the second.  No counterpart in the reference (Eigen's operator*). */
 int mpcx_ring_gemm_products(uint64_t r, uint64_t l, uint64_t c);
+/* mpcx_ring_gemm_u64 for callers that cannot allocate device memory (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments and results; the limb
+ * planes live in a file-scope device array of mpcx_ring_gemm_noalloc_limit() = 16 MiB per GPU (held until the process
+ * ends) instead of the context workspace, and the call makes no hipMalloc / hipFree and creates no events.  Always
+ * the digit-pair kernels.  Shapes whose planes (8 * (ceil128(r) + ceil128(c)) * min(ceil64(l), 8192) bytes) exceed the
+ * limit are rejected with an error, e.g. 1024 x 1024 x 1024 and 128 x 8192 x 128 fit.  Every call on a GPU shares that
+ * GPU's array: calls that overlap in time on one GPU (two contexts, two streams) race. */
+int mpcx_ring_gemm_u64_noalloc(mpcx_ctx *ctx, const int64_t *A, const int64_t *B, int64_t *C, uint64_t r, uint64_t l,
+                               uint64_t c, int layoutA, int layoutB, int layoutC, int accumulate);
+uint64_t mpcx_ring_gemm_noalloc_limit(void);
 int mpcx_ring_add(mpcx_ctx *ctx, const int64_t *a, const int64_t *b, int64_t *out, uint64_t n);
 int mpcx_ring_sub(mpcx_ctx *ctx, const int64_t *a, const int64_t *b, int64_t *out, uint64_t n);
 int mpcx_ring_sar(mpcx_ctx *ctx, const int64_t *a, int64_t *out, uint64_t n, int k); /* benchmark/benchmark1.cpp:106-112 */

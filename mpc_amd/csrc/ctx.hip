@@ -62,6 +62,11 @@ int mpcx_init(int device, mpcx_ctx **out) {
         return mpcx_fail(nullptr, "mpcx_init: stream creation failed: %s", hipGetErrorString(e));
     }
     ctx->own_stream = true;
+    if (ring_gemm_static_scratch_init(device)) {
+        (void)hipStreamDestroy(ctx->stream);
+        delete ctx;
+        return 1;
+    }
     *out = ctx;
     return 0;
 }

@@ -167,6 +167,8 @@ u64 ring_gemm_ws_bytes(int nparts, u64 r, u64 l, u64 c);
 // the same product through a residue number system (ring_gemm_rns.hip): 18 plain int8 products instead of 36
 bool ring_gemm_use_rns(u64 r, u64 l, u64 c);
 u32 gemm_group_rows(const char *env_name, u32 tiles_m);
+// looks up, once per device, the address of the file-scope scratch array of the entry point that allocates nothing
+int ring_gemm_static_scratch_init(int device);
 u64 ring_gemm_rns_ws_bytes(int nparts, u64 r, u64 l, u64 c);
 int ring_gemm_parts_rns(mpcx_ctx *ctx, const GemmPart *parts, int nparts, u64 r, u64 l, u64 c, int layA, int layB,
                         const i64 *add, const i64 *sub, i64 *Z, int layZ, int accumulate);

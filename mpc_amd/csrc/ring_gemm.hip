@@ -13,6 +13,7 @@
 // Limb planes are stored K-blocked: plane[i][kb][row][32 bytes], kb = k / 32, so that the operand
 // tile of one K step (a run of rows x 32 bytes) is one contiguous, fully used piece of memory.
 #include <cstdlib>
+#include <mutex>
 #include <type_traits>
 
 #include "mpcx_internal.h"
@@ -390,17 +391,36 @@ static u64 part_chunk_len(int nparts, u64 l) {
     return lc;
 }
 
-u64 ring_gemm_ws_bytes(int nparts, u64 r, u64 l, u64 c) {
-    if (ring_gemm_use_rns(r, l, c)) return ring_gemm_rns_ws_bytes(nparts, r, l, c);
+// limb planes of one accumulation chunk of the digit-pair kernels
+static u64 positional_ws_bytes(int nparts, u64 r, u64 l, u64 c) {
     const u64 Mp = round_up(r, RM), Np = round_up(c, RM), Kp = (u64)nparts * part_chunk_len(nparts, l);
     const u64 bytesA = 8 * Mp * Kp, bytesB = 8 * Np * Kp;
     return ((bytesA + 255) & ~255ull) + ((bytesB + 255) & ~255ull);
 }
 
+u64 ring_gemm_ws_bytes(int nparts, u64 r, u64 l, u64 c) {
+    if (ring_gemm_use_rns(r, l, c)) return ring_gemm_rns_ws_bytes(nparts, r, l, c);
+    return positional_ws_bytes(nparts, r, l, c);
+}
+
+static int ring_gemm_positional(mpcx_ctx *ctx, const GemmPart *parts, int nparts, u64 r, u64 l, u64 c, int layA, int layB,
+                                const i64 *add, const i64 *sub, i64 *Z, int layZ, int accumulate, void *ws);
+
 int ring_gemm_parts(mpcx_ctx *ctx, const GemmPart *parts, int nparts, u64 r, u64 l, u64 c, int layA, int layB,
                     const i64 *add, const i64 *sub, i64 *Z, int layZ, int accumulate) {
     if (r && l && c && ring_gemm_use_rns(r, l, c))
         return ring_gemm_parts_rns(ctx, parts, nparts, r, l, c, layA, layB, add, sub, Z, layZ, accumulate);
+    MPCX_REQUIRE(r > 0 && l > 0 && c > 0, "ring gemm: empty operand (r=%llu l=%llu c=%llu)", (unsigned long long)r,
+                 (unsigned long long)l, (unsigned long long)c);
+    void *ws;
+    MPCX_TRY(mpcx_ws(ctx, positional_ws_bytes(nparts, r, l, c), &ws));
+    return ring_gemm_positional(ctx, parts, nparts, r, l, c, layA, layB, add, sub, Z, layZ, accumulate, ws);
+}
+
+// the digit-pair kernels on a caller-provided workspace of positional_ws_bytes(..) bytes, 256-byte aligned; every byte
+// of the planes a chunk reads is written by that chunk's split launches, so the workspace needs no clearing
+static int ring_gemm_positional(mpcx_ctx *ctx, const GemmPart *parts, int nparts, u64 r, u64 l, u64 c, int layA, int layB,
+                                const i64 *add, const i64 *sub, i64 *Z, int layZ, int accumulate, void *ws) {
     MPCX_REQUIRE(r > 0 && l > 0 && c > 0, "ring gemm: empty operand (r=%llu l=%llu c=%llu)", (unsigned long long)r,
                  (unsigned long long)l, (unsigned long long)c);
     MPCX_REQUIRE(r < (1u << 30) && c < (1u << 30) && l < (1u << 30), "ring gemm: dimension too large");
@@ -411,12 +431,9 @@ int ring_gemm_parts(mpcx_ctx *ctx, const GemmPart *parts, int nparts, u64 r, u64
     const u64 Kp = (u64)nparts * lc;
     MPCX_REQUIRE(Kp <= 8192, "ring gemm: cannot chunk K");
     MPCX_REQUIRE(Mp / 64 <= 65535 && Np / 64 <= 65535, "ring gemm: more than 4194240 rows or columns"); // split grid y
-    const u64 bytesA = 8 * Mp * Kp, bytesB = 8 * Np * Kp;
-    void *ws;
-    MPCX_TRY(mpcx_ws(ctx, ring_gemm_ws_bytes(nparts, r, l, c), &ws));
+    const u64 bytesA = 8 * Mp * Kp;
     i8 *Apl = (i8 *)ws;
     i8 *Bpl = Apl + ((bytesA + 255) & ~255ull);
-    (void)bytesB;
     const u32 tiles_m = (u32)(Mp / RM), tiles_n = (u32)(Np / RN);
     const u32 nkb = (u32)(Kp / RK);
     const u64 soA = layA ? 1 : l, skA = layA ? r : 1; // A(o=row, k)
@@ -481,7 +498,56 @@ int ring_gemm_parts(mpcx_ctx *ctx, const GemmPart *parts, int nparts, u64 r, u64
     return 0;
 }
 
+// ---- the entry point that allocates nothing: limb planes in a file-scope device array.  Every GPU holds its own
+// copy of the array at its own address; the address is looked up once per device, with that device current, and
+// only that pointer (never the array's name) is handed to kernels.
+constexpr u64 STATIC_SCRATCH_BYTES = 16ull << 20;
+static __device__ __align__(256) unsigned char scratch[STATIC_SCRATCH_BYTES];
+constexpr int MAX_DEVICES = 64;
+static void *g_scratch_ptr[MAX_DEVICES];
+static std::mutex g_scratch_mu;
+
+int ring_gemm_static_scratch_init(int device) {
+    mpcx_ctx *ctx = nullptr; // errors of a context that does not exist yet go to the init error slot
+    MPCX_REQUIRE(device >= 0 && device < MAX_DEVICES, "mpcx_init: device %d beyond the %d the static scratch table holds",
+                 device, MAX_DEVICES);
+    std::lock_guard<std::mutex> g(g_scratch_mu);
+    if (g_scratch_ptr[device]) return 0;
+    MPCX_HIP(hipSetDevice(device));
+    void *ptr = nullptr;
+    MPCX_HIP(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+    MPCX_REQUIRE(ptr && ((uintptr_t)ptr & 255) == 0, "mpcx_init: static scratch of device %d at %p is not 256-byte aligned",
+                 device, ptr);
+    g_scratch_ptr[device] = ptr;
+    return 0;
+}
+
 extern "C" {
+
+int mpcx_ring_gemm_u64_noalloc(mpcx_ctx *ctx, const int64_t *A, const int64_t *B, int64_t *C, uint64_t r, uint64_t l,
+                               uint64_t c, int layoutA, int layoutB, int layoutC, int accumulate) {
+    MPCX_REQUIRE(ctx, "mpcx_ring_gemm_u64_noalloc: the context is NULL");
+    MPCX_REQUIRE(A && B && C, "mpcx_ring_gemm_u64_noalloc: NULL operand");
+    MPCX_REQUIRE(r > 0 && l > 0 && c > 0 && r < (1u << 30) && c < (1u << 30) && l < (1u << 30),
+                 "mpcx_ring_gemm_u64_noalloc: bad shape (r=%llu l=%llu c=%llu)", (unsigned long long)r,
+                 (unsigned long long)l, (unsigned long long)c);
+    const u64 need = positional_ws_bytes(1, r, l, c);
+    MPCX_REQUIRE(need <= STATIC_SCRATCH_BYTES,
+                 "mpcx_ring_gemm_u64_noalloc: a %llu x %llu . %llu x %llu product needs %llu bytes of limb planes, the "
+                 "static scratch holds %llu (use mpcx_ring_gemm_u64)",
+                 (unsigned long long)r, (unsigned long long)l, (unsigned long long)l, (unsigned long long)c,
+                 (unsigned long long)need, (unsigned long long)STATIC_SCRATCH_BYTES);
+    void *ws = g_scratch_ptr[ctx->device]; // looked up by mpcx_init of this device
+    MPCX_REQUIRE(ws, "mpcx_ring_gemm_u64_noalloc: the static scratch of device %d was not set up", ctx->device);
+    const bool prof = ctx->prof; // the profiling scopes create HIP events, which may allocate
+    ctx->prof = false;
+    GemmPart p{A, B, nullptr};
+    const int rc = ring_gemm_positional(ctx, &p, 1, r, l, c, layoutA, layoutB, nullptr, nullptr, C, layoutC, accumulate, ws);
+    ctx->prof = prof;
+    return rc;
+}
+
+uint64_t mpcx_ring_gemm_noalloc_limit(void) { return STATIC_SCRATCH_BYTES; }
 
 int mpcx_ring_gemm_u64(mpcx_ctx *ctx, const int64_t *A, const int64_t *B, int64_t *C, uint64_t r, uint64_t l,
                        uint64_t c, int layoutA, int layoutB, int layoutC, int accumulate) {
