@@ -143,18 +143,28 @@ int mpcx_aby3_add_prepare_step2(mpcx_ctx *ctx, const int64_t *X0, const int64_t 
 /* msb (:361-467), six rounds temp = 32,16,8,4,2,1.  The carry tree is kept as dense bit strings (bit
  * 2*temp*k + b of a level's string = the reference's byte k*2*temp+b) that halve every round; `state` is an
  * opaque scratch of 6*n 64-bit words owned by the caller for the duration of one msb.
- *  begin:      records the inputs; G0, G1, P0, P1 are read in place by the temp = 32 round (with :385-387,
- *              G[63]=0, P[63]=1, applied on the fly) and must stay unchanged until its round_post has run
+ *  begin:      records (in the context) where the inputs live; G0, G1, P0, P1 are read in place by the temp = 32
+ *              round (with :385-387, G[63]=0, P[63]=1, applied on the fly) and must stay unchanged until its
+ *              round_post / round_mid has run; the rounds of a state buffer go through the context that began it
  *  round_pre:  builds this round's vecbool_mul product share (:397-414, :253-256), writes it to msg_out
  *              (2*temp bytes per element, the byte order of result[0]) and advances share 0 of the state
  *  round_post: msg_in = result[1] received from next; advances share 1 of the state (:416-428)
- *  final:      Z_i = G_i ^ backup_i (:459-466); P0_in/P1_in are the msb() inputs (bit 63 = backup) */
+ *  final:      Z_i = G_i ^ backup_i (:459-466); P0_in/P1_in are the msb() inputs (bit 63 = backup)
+ * One call per local segment between two messenger rounds: round_pre(32) before the first round, then
+ *  round_mid:  for temp = 32,16,8,4,2: msg_in = result[1] of round temp; the same state and msg_out as
+ *              round_post(temp) followed by round_pre(temp / 2), in one pass (share 1 of the level in between
+ *              stays in registers)
+ *  last:       msg_in = result[1] of round 1; the same Z as round_post(1) followed by final (the backup bits are
+ *              read from the state, where round_pre(32) keeps them) */
 int mpcx_aby3_msb_begin(mpcx_ctx *ctx, const int64_t *G0, const int64_t *G1, const int64_t *P0, const int64_t *P1,
                         uint64_t n, uint64_t *state);
 int mpcx_aby3_msb_round_pre(mpcx_ctx *ctx, uint64_t *state, uint64_t n, uint64_t temp, int8_t *msg_out);
 int mpcx_aby3_msb_round_post(mpcx_ctx *ctx, uint64_t *state, uint64_t n, uint64_t temp, const int8_t *msg_in);
 int mpcx_aby3_msb_final(mpcx_ctx *ctx, const uint64_t *state, const int64_t *P0_in, const int64_t *P1_in, uint64_t n,
                         int8_t *Z0, int8_t *Z1);
+int mpcx_aby3_msb_round_mid(mpcx_ctx *ctx, uint64_t *state, uint64_t n, uint64_t temp, const int8_t *msg_in,
+                            int8_t *msg_out);
+int mpcx_aby3_msb_last(mpcx_ctx *ctx, const uint64_t *state, uint64_t n, const int8_t *msg_in, int8_t *Z0, int8_t *Z1);
 /* trunc before the round (:480-503); seed12/pop12 = the stream parties 1 and 2 share */
 int mpcx_aby3_trunc_local(mpcx_ctx *ctx, int party, const int64_t *X0, const int64_t *X1, uint64_t n, int number,
                           uint64_t seed12, uint64_t pop12, int64_t *Y0);

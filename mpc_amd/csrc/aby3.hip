@@ -37,6 +37,10 @@ inline u64 msb_stride(u64 n, u32 temp) {
     return (ceil_div(bits, 8) + 3) & ~3ull; // whole 32-bit words
 }
 inline u64 msb_base(u64 n, u32 temp) { return (temp == 32 || temp == 8 || temp == 2 || temp == 0) ? 0 : 32 * n; }
+// the backup bits of P0 / P1 (bit 63 of every element, :385): two arrays of one byte per element behind the levels of
+// the lower region (the largest of them, level 8, ends at or before byte 16 n)
+inline u64 msb_backup_base(u64 n) { return 16 * n; }
+inline u64 msb_backup_stride(u64 n) { return (n + 7) & ~7ull; }
 
 // bits 0,2,4,.. of x moved to bits 0,1,2,..
 __device__ inline u32 compress_even(u32 x) {
@@ -61,40 +65,76 @@ __device__ inline u32 bytes_to_nibble(u32 w) {
 // result bit 2m+1 = share of P[2m+1] & P[2m], shared AND = (x0&y0)^(x1&y0)^(x0&y1) without re-randomisation (:255).
 // The result string goes out as one byte per bit; share 0 of the next level (:424-425 with i = 0) is
 // G' = result_even ^ G_odd, P' = result_odd, compacted.
-// word i of share array `arr` of the level a round reads.  FIRST (level 32): `in` holds the addresses of the
-// caller's G0, G1, P0, P1; bit 63 of every element (bit 31 of the odd words) is forced to 0 in G and 1 in P.
-template <bool FIRST> __device__ inline u32 msb_in_word(const u8 *in, u64 sin, u32 arr, u64 i) {
-    if (!FIRST) return ((const u32 *)(in + arr * sin))[i];
-    const u32 v = ((const u32 *)((const u64 *)in)[arr])[i];
-    if (!(i & 1)) return v;
+//
+// The four share arrays a round reads: G0, G1, P0, P1 as 32-bit words.  FIRST (level 32): the caller's own G / P
+// words, with bit 63 of every element (bit 31 of the odd words) forced to 0 in G and 1 in P.
+struct MsbIn {
+    const u32 *a[4];
+};
+template <bool FIRST> __device__ inline u32 msb_in_word(const MsbIn &in, u32 arr, u64 i) {
+    const u32 v = in.a[arr][i];
+    if (!FIRST || !(i & 1)) return v;
     return arr < 2 ? v & 0x7FFFFFFFu : v | 0x80000000u;
 }
+// 32 bits of a result string -> its 32 wire bytes
+template <bool ALIGNED16> __device__ inline void msb_put32(u8 *dst, u32 r) {
+    u32 w[8];
+#pragma unroll
+    for (u32 q = 0; q < 8; q++) w[q] = nibble_to_bytes(r >> (4 * q));
+    if (ALIGNED16) {
+        *(uint4 *)dst = make_uint4(w[0], w[1], w[2], w[3]);
+        *(uint4 *)(dst + 16) = make_uint4(w[4], w[5], w[6], w[7]);
+    } else {
+#pragma unroll
+        for (u32 q = 0; q < 4; q++) *(uint2 *)(dst + 8 * q) = make_uint2(w[2 * q], w[2 * q + 1]);
+    }
+}
+// 32 wire bytes -> 32 bits
+template <bool ALIGNED16> __device__ inline u32 msb_get32(const u8 *src) {
+    u32 w[8];
+    if (ALIGNED16) {
+        const uint4 a = *(const uint4 *)src, b = *(const uint4 *)(src + 16);
+        w[0] = a.x, w[1] = a.y, w[2] = a.z, w[3] = a.w, w[4] = b.x, w[5] = b.y, w[6] = b.z, w[7] = b.w;
+    } else {
+#pragma unroll
+        for (u32 q = 0; q < 4; q++) {
+            const uint2 a = *(const uint2 *)(src + 8 * q);
+            w[2 * q] = a.x, w[2 * q + 1] = a.y;
+        }
+    }
+    u32 r = 0;
+#pragma unroll
+    for (u32 q = 0; q < 8; q++) r |= bytes_to_nibble(w[q]) << (4 * q);
+    return r;
+}
+// the product share of one round on 32 bits of the four arrays: even result bits in re, odd ones (unshifted) in ro
+__device__ inline void msb_and32(u32 g0, u32 g1, u32 p0, u32 p1, u32 &re, u32 &ro) {
+    constexpr u32 E = 0x55555555u;
+    const u32 po0 = (p0 >> 1) & E, po1 = (p1 >> 1) & E;
+    const u32 ge0 = g0 & E, ge1 = g1 & E, pe0 = p0 & E, pe1 = p1 & E;
+    re = (po0 & ge0) ^ (po1 & ge0) ^ (po0 & ge1);
+    ro = (po0 & pe0) ^ (po1 & pe0) ^ (po0 & pe1);
+}
 
+// FIRST also keeps bit 63 of every P word (`backup`, :385) in two byte arrays bk0 / bk1 for the output step.
 template <bool ALIGNED16, bool FIRST>
-__global__ __launch_bounds__(256) void msb_round_pre_kernel(const u8 *__restrict__ in, u64 sin, u8 *__restrict__ out,
-                                                            u64 sout, u64 nbits, u8 *__restrict__ msg) {
+__global__ __launch_bounds__(256) void msb_round_pre_kernel(MsbIn in, u8 *__restrict__ out, u64 sout, u64 nbits,
+                                                            u8 *__restrict__ msg, u8 *__restrict__ bk0,
+                                                            u8 *__restrict__ bk1) {
     constexpr u32 E = 0x55555555u;
     const u64 words = (nbits + 31) / 32;
     for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < words; i += (u64)gridDim.x * 256) {
-        const u32 g0 = msb_in_word<FIRST>(in, sin, 0, i), g1 = msb_in_word<FIRST>(in, sin, 1, i);
-        const u32 p0 = msb_in_word<FIRST>(in, sin, 2, i), p1 = msb_in_word<FIRST>(in, sin, 3, i);
-        const u32 po0 = (p0 >> 1) & E, po1 = (p1 >> 1) & E;
-        const u32 ge0 = g0 & E, ge1 = g1 & E, pe0 = p0 & E, pe1 = p1 & E;
-        const u32 re = (po0 & ge0) ^ (po1 & ge0) ^ (po0 & ge1);
-        const u32 ro = (po0 & pe0) ^ (po1 & pe0) ^ (po0 & pe1);
+        const u32 g0 = msb_in_word<FIRST>(in, 0, i), g1 = msb_in_word<FIRST>(in, 1, i);
+        const u32 p0 = msb_in_word<FIRST>(in, 2, i), p1 = msb_in_word<FIRST>(in, 3, i);
+        if (FIRST && (i & 1)) { // the raw top bits (msb_in_word has forced them to 1)
+            bk0[i >> 1] = (u8)(in.a[2][i] >> 31);
+            bk1[i >> 1] = (u8)(in.a[3][i] >> 31);
+        }
+        u32 re, ro;
+        msb_and32(g0, g1, p0, p1, re, ro);
         const u32 r = re | (ro << 1);
-        u32 w[8];
-#pragma unroll
-        for (u32 q = 0; q < 8; q++) w[q] = nibble_to_bytes(r >> (4 * q));
-        u8 *dst = msg + 32 * i;
         if (32 * i + 32 <= nbits) {
-            if (ALIGNED16) {
-                *(uint4 *)dst = make_uint4(w[0], w[1], w[2], w[3]);
-                *(uint4 *)(dst + 16) = make_uint4(w[4], w[5], w[6], w[7]);
-            } else {
-#pragma unroll
-                for (u32 q = 0; q < 4; q++) *(uint2 *)(dst + 8 * q) = make_uint2(w[2 * q], w[2 * q + 1]);
-            }
+            msb_put32<ALIGNED16>(msg + 32 * i, r);
         } else {
             for (u64 t = 32 * i; t < nbits; t++) msg[t] = (u8)((r >> (t & 31)) & 1u);
         }
@@ -107,34 +147,103 @@ __global__ __launch_bounds__(256) void msb_round_pre_kernel(const u8 *__restrict
 // After the round (:416-428 with i = 1): msg = result[1] from the next party, packed back into bits; share 1 of the
 // next level is written.
 template <bool ALIGNED16, bool FIRST>
-__global__ __launch_bounds__(256) void msb_round_post_kernel(const u8 *__restrict__ in, u64 sin, u8 *__restrict__ out,
-                                                             u64 sout, u64 nbits, const u8 *__restrict__ msg) {
+__global__ __launch_bounds__(256) void msb_round_post_kernel(MsbIn in, u8 *__restrict__ out, u64 sout, u64 nbits,
+                                                             const u8 *__restrict__ msg) {
     constexpr u32 E = 0x55555555u;
     const u64 words = (nbits + 31) / 32;
     for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < words; i += (u64)gridDim.x * 256) {
-        const u8 *src = msg + 32 * i;
         u32 r = 0;
         if (32 * i + 32 <= nbits) {
-            u32 w[8];
-            if (ALIGNED16) {
-                const uint4 a = *(const uint4 *)src, b = *(const uint4 *)(src + 16);
-                w[0] = a.x, w[1] = a.y, w[2] = a.z, w[3] = a.w, w[4] = b.x, w[5] = b.y, w[6] = b.z, w[7] = b.w;
-            } else {
-#pragma unroll
-                for (u32 q = 0; q < 4; q++) {
-                    const uint2 a = *(const uint2 *)(src + 8 * q);
-                    w[2 * q] = a.x, w[2 * q + 1] = a.y;
-                }
-            }
-#pragma unroll
-            for (u32 q = 0; q < 8; q++) r |= bytes_to_nibble(w[q]) << (4 * q);
+            r = msb_get32<ALIGNED16>(msg + 32 * i);
         } else {
             for (u64 t = 32 * i; t < nbits; t++) r |= (u32)(msg[t] & 1) << (t & 31);
         }
-        const u32 g1 = msb_in_word<FIRST>(in, sin, 1, i);
+        const u32 g1 = msb_in_word<FIRST>(in, 1, i);
         if (2 * i + 2 <= sout) {
             *(u16 *)(out + sout + 2 * i) = (u16)compress_even((r & E) ^ ((g1 >> 1) & E));
             *(u16 *)(out + 3 * sout + 2 * i) = (u16)compress_even((r >> 1) & E);
+        }
+    }
+}
+// The whole local segment between two messenger rounds of the tree: what round_post(T) and round_pre(T / 2) do, in
+// one pass and without storing the level in between.  A lane takes 64 bits of the level-T strings: the 64 wire
+// bytes of result[1] and the 64 bits of G1 give 32 bits of share 1 of level T/2 (:416-428), which stay in registers;
+// with the 32 bits of share 0 that the previous segment stored they give this party's product share of round T/2
+// (:397-414, :253-256) -- 32 wire bytes -- and 16 bits of share 0 of level T/4.  Of share 1 only G is stored (the
+// next segment reads its odd bits); P1 of a level is never needed again.
+template <bool ALIGNED16, bool FIRST>
+__global__ __launch_bounds__(256) void msb_round_mid_kernel(const u32 *__restrict__ g1_in, u64 g1_words,
+                                                            u8 *__restrict__ half, u64 shalf, u8 *__restrict__ quarter,
+                                                            u64 squarter, u64 nbits, const u8 *__restrict__ msg_in,
+                                                            u8 *__restrict__ msg_out) {
+    constexpr u32 E = 0x55555555u;
+    const u64 lanes = (nbits + 63) / 64;
+    const u64 hbits = nbits / 2; // bits of a level-T/2 string = bytes of the outgoing message
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < lanes; i += (u64)gridDim.x * 256) {
+        u32 rlo = 0, rhi = 0;
+        if (64 * i + 64 <= nbits) {
+            rlo = msb_get32<ALIGNED16>(msg_in + 64 * i);
+            rhi = msb_get32<ALIGNED16>(msg_in + 64 * i + 32);
+        } else {
+            for (u64 t = 64 * i; t < nbits; t++) {
+                const u32 b = (u32)(msg_in[t] & 1);
+                if ((t & 63) < 32)
+                    rlo |= b << (t & 31);
+                else
+                    rhi |= b << (t & 31);
+            }
+        }
+        u32 glo = g1_in[2 * i], ghi = 2 * i + 1 < g1_words ? g1_in[2 * i + 1] : 0;
+        if (FIRST) ghi &= 0x7FFFFFFFu;
+        // share 1 of level T/2
+        const u32 G1h = compress_even((rlo & E) ^ ((glo >> 1) & E)) | compress_even((rhi & E) ^ ((ghi >> 1) & E)) << 16;
+        const u32 P1h = compress_even((rlo >> 1) & E) | compress_even((rhi >> 1) & E) << 16;
+        ((u32 *)(half + shalf))[i] = G1h;
+        const u32 G0h = ((const u32 *)half)[i], P0h = ((const u32 *)(half + 2 * shalf))[i];
+        u32 re, ro;
+        msb_and32(G0h, G1h, P0h, P1h, re, ro);
+        const u32 r = re | (ro << 1);
+        if (32 * i + 32 <= hbits) {
+            msb_put32<ALIGNED16>(msg_out + 32 * i, r);
+        } else {
+            for (u64 t = 32 * i; t < hbits; t++) msg_out[t] = (u8)((r >> (t & 31)) & 1u);
+        }
+        if (2 * i + 2 <= squarter) {
+            *(u16 *)(quarter + 2 * i) = (u16)compress_even(re ^ ((G0h >> 1) & E));
+            *(u16 *)(quarter + 2 * squarter + 2 * i) = (u16)compress_even(ro);
+        }
+    }
+}
+// The segment after the last round: round_post(1) and the output step (:459-466) in one pass, eight elements per
+// lane.  msg = result[1] of round 1 (two bytes per element); g1_lvl1 = G1 of level 1 (two bits per element),
+// g0_lvl0 = G0 of level 0 (one bit per element); bk0 / bk1 = the backup bytes the first round kept.
+template <bool ALIGNED>
+__global__ __launch_bounds__(256) void msb_last_kernel(const u8 *__restrict__ g1_lvl1, const u8 *__restrict__ g0_lvl0,
+                                                       const u8 *__restrict__ msg, const u8 *__restrict__ bk0,
+                                                       const u8 *__restrict__ bk1, u64 n, u8 *__restrict__ Z0,
+                                                       u8 *__restrict__ Z1) {
+    const u64 groups = (n + 7) / 8;
+    for (u64 q = (u64)blockIdx.x * 256 + threadIdx.x; q < groups; q += (u64)gridDim.x * 256) {
+        const u64 k0 = 8 * q;
+        const u32 g1w = g1_lvl1[2 * q] | (k0 + 4 < n ? (u32)g1_lvl1[2 * q + 1] << 8 : 0), g0w = g0_lvl0[q];
+        if (ALIGNED && k0 + 8 <= n) {
+            const uint4 m = *(const uint4 *)(msg + 2 * k0);
+            const u32 mw[4] = {m.x, m.y, m.z, m.w};
+            u64 z0 = *(const u64 *)(bk0 + k0), z1 = *(const u64 *)(bk1 + k0);
+#pragma unroll
+            for (u32 e = 0; e < 8; e++) {
+                const u64 g1 = ((mw[e >> 1] >> (16 * (e & 1))) & 1u) ^ ((g1w >> (2 * e + 1)) & 1u); // :424 with i = 1
+                z0 ^= (u64)((g0w >> e) & 1u) << (8 * e);
+                z1 ^= g1 << (8 * e);
+            }
+            *(u64 *)(Z0 + k0) = z0;
+            *(u64 *)(Z1 + k0) = z1;
+        } else {
+            for (u64 k = k0; k < n && k < k0 + 8; k++) {
+                const u32 e = (u32)(k - k0);
+                Z0[k] = (u8)(((g0w >> e) & 1u) ^ bk0[k]);
+                Z1[k] = (u8)(((u32)(msg[2 * k] & 1) ^ ((g1w >> (2 * e + 1)) & 1u)) ^ bk1[k]);
+            }
         }
     }
 }
@@ -280,14 +389,27 @@ int mpcx_aby3_msb_begin(mpcx_ctx *ctx, const int64_t *G0, const int64_t *G1, con
                         uint64_t n, uint64_t *state) {
     if (n == 0) return 0;
     MPCX_REQUIRE(G0 && G1 && P0 && P1 && state, "mpcx_aby3_msb_begin: NULL pointer");
-    const u64 a0 = (u64)(uintptr_t)G0, a1 = (u64)(uintptr_t)G1, a2 = (u64)(uintptr_t)P0, a3 = (u64)(uintptr_t)P1;
-    return ew_launch(ctx, 1, [=] __device__(u64) { state[0] = a0, state[1] = a1, state[2] = a2, state[3] = a3; });
+    // the first level is read in place: remember where it lives (host side, per state buffer)
+    ctx->msb_inputs[state] = {G0, G1, P0, P1};
+    return 0;
 }
 static int msb_round_check(mpcx_ctx *ctx, const char *who, const void *state, const void *msg, uint64_t temp) {
     MPCX_REQUIRE(state && msg, "%s: NULL pointer", who);
     MPCX_REQUIRE(temp == 32 || temp == 16 || temp == 8 || temp == 4 || temp == 2 || temp == 1,
                  "%s: temp must be one of 32,16,8,4,2,1", who);
     MPCX_REQUIRE(((uintptr_t)msg & 7) == 0, "%s: the message must be 8-byte aligned", who);
+    return 0;
+}
+// the four arrays the round with `temp` pairs reads
+static int msb_level_in(mpcx_ctx *ctx, const char *who, const uint64_t *state, uint64_t n, uint64_t temp, MsbIn *in) {
+    if (temp == 32) {
+        auto it = ctx->msb_inputs.find(state);
+        MPCX_REQUIRE(it != ctx->msb_inputs.end(), "%s: mpcx_aby3_msb_begin was not called for this state buffer", who);
+        for (int k = 0; k < 4; k++) in->a[k] = (const u32 *)it->second[k];
+        return 0;
+    }
+    const u8 *base = (const u8 *)state + msb_base(n, (u32)temp);
+    for (int k = 0; k < 4; k++) in->a[k] = (const u32 *)(base + k * msb_stride(n, (u32)temp));
     return 0;
 }
 // launches KERNEL<16-byte aligned message, first level> for the round with `temp` pairs
@@ -297,44 +419,111 @@ static int msb_round_check(mpcx_ctx *ctx, const char *who, const void *state, co
         const u32 T = (u32)temp;                                                                                       \
         const u64 nbits = 2 * temp * n;                                                                                \
         const dim3 grid(grid_for(ceil_div(nbits, 32))), block(256);                                                    \
-        const u8 *in = T == 32 ? st : st + msb_base(n, T);                                                             \
-        const u64 sin = msb_stride(n, T), sout = msb_stride(n, T / 2);                                                 \
+        const u64 sout = msb_stride(n, T / 2);                                                                         \
         u8 *out = st + msb_base(n, T / 2);                                                                             \
         const bool a16 = ((uintptr_t)(MSG) & 15) == 0;                                                                 \
         if (a16 && T == 32)                                                                                            \
-            hipLaunchKernelGGL((KERNEL<true, true>), grid, block, 0, ctx->stream, in, sin, out, sout, nbits, MSG);       \
+            hipLaunchKernelGGL((KERNEL<true, true>), grid, block, 0, ctx->stream, in, out, sout, nbits, MSG EXTRA);      \
         else if (a16)                                                                                                  \
-            hipLaunchKernelGGL((KERNEL<true, false>), grid, block, 0, ctx->stream, in, sin, out, sout, nbits, MSG);      \
+            hipLaunchKernelGGL((KERNEL<true, false>), grid, block, 0, ctx->stream, in, out, sout, nbits, MSG EXTRA);     \
         else if (T == 32)                                                                                              \
-            hipLaunchKernelGGL((KERNEL<false, true>), grid, block, 0, ctx->stream, in, sin, out, sout, nbits, MSG);      \
+            hipLaunchKernelGGL((KERNEL<false, true>), grid, block, 0, ctx->stream, in, out, sout, nbits, MSG EXTRA);     \
         else                                                                                                           \
-            hipLaunchKernelGGL((KERNEL<false, false>), grid, block, 0, ctx->stream, in, sin, out, sout, nbits, MSG);     \
+            hipLaunchKernelGGL((KERNEL<false, false>), grid, block, 0, ctx->stream, in, out, sout, nbits, MSG EXTRA);    \
     } while (0)
 int mpcx_aby3_msb_round_pre(mpcx_ctx *ctx, uint64_t *state, uint64_t n, uint64_t temp, int8_t *msg_out) {
     if (n == 0) return 0;
     MPCX_TRY(msb_round_check(ctx, "mpcx_aby3_msb_round_pre", state, msg_out, temp));
+    MsbIn in;
+    MPCX_TRY(msb_level_in(ctx, "mpcx_aby3_msb_round_pre", state, n, temp, &in));
     ProfScope ps(ctx, PROF_MSB);
+    u8 *bk0 = (u8 *)state + msb_backup_base(n), *bk1 = bk0 + msb_backup_stride(n);
+#define EXTRA , bk0, bk1
     MSB_ROUND_LAUNCH(msb_round_pre_kernel, (u8 *)msg_out);
+#undef EXTRA
     MPCX_LAUNCH_CHECK();
     return 0;
 }
 int mpcx_aby3_msb_round_post(mpcx_ctx *ctx, uint64_t *state, uint64_t n, uint64_t temp, const int8_t *msg_in) {
     if (n == 0) return 0;
     MPCX_TRY(msb_round_check(ctx, "mpcx_aby3_msb_round_post", state, msg_in, temp));
+    MsbIn in;
+    MPCX_TRY(msb_level_in(ctx, "mpcx_aby3_msb_round_post", state, n, temp, &in));
     ProfScope ps(ctx, PROF_MSB);
+#define EXTRA
     MSB_ROUND_LAUNCH(msb_round_post_kernel, (const u8 *)msg_in);
+#undef EXTRA
     MPCX_LAUNCH_CHECK();
     return 0;
 }
 #undef MSB_ROUND_LAUNCH
+int mpcx_aby3_msb_round_mid(mpcx_ctx *ctx, uint64_t *state, uint64_t n, uint64_t temp, const int8_t *msg_in,
+                            int8_t *msg_out) {
+    if (n == 0) return 0;
+    MPCX_TRY(msb_round_check(ctx, "mpcx_aby3_msb_round_mid", state, msg_in, temp));
+    MPCX_REQUIRE(temp != 1, "mpcx_aby3_msb_round_mid: temp = 1 is the last round (mpcx_aby3_msb_last)");
+    MPCX_REQUIRE(msg_out && ((uintptr_t)msg_out & 7) == 0, "mpcx_aby3_msb_round_mid: msg_out must be 8-byte aligned");
+    const u32 T = (u32)temp;
+    const u64 nbits = 2 * temp * n;
+    if (nbits < 4096) {
+        // A handful of lanes: the word-rounded arrays of level T and level T/4 may share bytes of the state, which
+        // the one-pass kernel would write while other lanes still read them.  Two passes, as the separate calls do.
+        MPCX_TRY(mpcx_aby3_msb_round_post(ctx, state, n, temp, msg_in));
+        return mpcx_aby3_msb_round_pre(ctx, state, n, temp / 2, msg_out);
+    }
+    MsbIn in;
+    MPCX_TRY(msb_level_in(ctx, "mpcx_aby3_msb_round_mid", state, n, temp, &in));
+    u8 *st = (u8 *)state;
+    u8 *half = st + msb_base(n, T / 2), *quarter = st + msb_base(n, T / 4);
+    const u64 shalf = msb_stride(n, T / 2), squarter = msb_stride(n, T / 4);
+    const u64 g1_words = T == 32 ? 2 * n : msb_stride(n, T) / 4;
+    const dim3 grid(grid_for(ceil_div(nbits, 64))), block(256);
+    const bool a16 = (((uintptr_t)msg_in | (uintptr_t)msg_out) & 15) == 0;
+    const u8 *mi = (const u8 *)msg_in;
+    u8 *mo = (u8 *)msg_out;
+    ProfScope ps(ctx, PROF_MSB);
+#define MSB_MID(A16, FIRST)                                                                                            \
+    hipLaunchKernelGGL((msb_round_mid_kernel<A16, FIRST>), grid, block, 0, ctx->stream, in.a[1], g1_words, half, shalf,   \
+                       quarter, squarter, nbits, mi, mo)
+    if (a16 && T == 32)
+        MSB_MID(true, true);
+    else if (a16)
+        MSB_MID(true, false);
+    else if (T == 32)
+        MSB_MID(false, true);
+    else
+        MSB_MID(false, false);
+#undef MSB_MID
+    MPCX_LAUNCH_CHECK();
+    return 0;
+}
 int mpcx_aby3_msb_final(mpcx_ctx *ctx, const uint64_t *state, const int64_t *P0_in, const int64_t *P1_in, uint64_t n,
                         int8_t *Z0, int8_t *Z1) {
     MPCX_REQUIRE((state && P0_in && P1_in && Z0 && Z1) || n == 0, "mpcx_aby3_msb_final: NULL pointer");
+    ctx->msb_inputs.erase(state);
     const u8 *g0 = (const u8 *)state + msb_base(n, 0), *g1 = g0 + msb_stride(n, 0);
     return ew_launch(ctx, n, [=] __device__(u64 i) { // level 0: one bit per element and array
         Z0[i] = (i8)(((g0[i >> 3] >> (i & 7)) & 1) ^ ((u64)P0_in[i] >> 63));
         Z1[i] = (i8)(((g1[i >> 3] >> (i & 7)) & 1) ^ ((u64)P1_in[i] >> 63));
     });
+}
+int mpcx_aby3_msb_last(mpcx_ctx *ctx, const uint64_t *state, uint64_t n, const int8_t *msg_in, int8_t *Z0, int8_t *Z1) {
+    if (n == 0) return 0;
+    MPCX_REQUIRE(state && msg_in && Z0 && Z1, "mpcx_aby3_msb_last: NULL pointer");
+    ctx->msb_inputs.erase(state);
+    const u8 *st = (const u8 *)state;
+    const u8 *g1_lvl1 = st + msb_base(n, 1) + msb_stride(n, 1), *g0_lvl0 = st + msb_base(n, 0);
+    ProfScope ps(ctx, PROF_MSB);
+    const u8 *bk0 = st + msb_backup_base(n), *bk1 = bk0 + msb_backup_stride(n);
+    const dim3 grid(grid_for(ceil_div(n, 8))), block(256);
+    if ((((uintptr_t)msg_in & 15) | (((uintptr_t)Z0 | (uintptr_t)Z1) & 7)) == 0)
+        hipLaunchKernelGGL(msb_last_kernel<true>, grid, block, 0, ctx->stream, g1_lvl1, g0_lvl0, (const u8 *)msg_in, bk0, bk1, n,
+                           (u8 *)Z0, (u8 *)Z1);
+    else
+        hipLaunchKernelGGL(msb_last_kernel<false>, grid, block, 0, ctx->stream, g1_lvl1, g0_lvl0, (const u8 *)msg_in, bk0, bk1,
+                           n, (u8 *)Z0, (u8 *)Z1);
+    MPCX_LAUNCH_CHECK();
+    return 0;
 }
 
 int mpcx_aby3_trunc_local(mpcx_ctx *ctx, int party, const int64_t *X0, const int64_t *X1, uint64_t n, int number,
@@ -357,7 +546,7 @@ int mpcx_aby3_trunc_local(mpcx_ctx *ctx, int party, const int64_t *X0, const int
 // s01 the same again for the second OT.  Every use of those words is fused with their regeneration (prg_map.h):
 //   * masks C: one word per element; the two C words an element needs come from two streams in one pass;
 //   * W pairs: element e owns words 2e, 2e+1 of its section; word index w is (e = w >> 1, t = w & 1).
-// The two plain OT messages M_0, M_1 of a sender go through 16*n bytes of scratch between the passes.
+// A sender's whole segment before the round is one pass (bi_sender_pre_kernel): nothing is staged in memory.
 } // extern "C"
 namespace {
 struct BiGeom {
@@ -366,19 +555,205 @@ struct BiGeom {
     u64 c(u64 base) const { return base + i0; }
     u64 w(u64 base) const { return base + nt + 2 * i0; }
 };
-// out[t * n + e] = M[t * n + e] ^ W_t[e]: both masked OT messages of a sender from one pass over its pair words
-int bi_mask_pairs(mpcx_ctx *ctx, u64 seed, u64 t_first, u64 n, const u64 *M, u64 *out) {
-    return prg_map1(ctx, seed, t_first, 2 * n, [=] __device__(u64 w, u64 v) {
-        const u64 k = (w & 1) * n + (w >> 1);
-        out[k] = M[k] ^ v;
-    });
+// A generator positioned anywhere in a stream: starts from the checkpoint below word t and discards the words in
+// between.  Every lane of a launch opens a section at words that differ by multiples of PRG_CK, so the number of
+// discarded words is the same for all of them.
+struct BiGen {
+    u64 s = 0, l = 0, h = 0;
+    __device__ void open(const PrgCk *__restrict__ ck, u64 t, bool active) {
+        if (active) {
+            const PrgCk c = ck[t / PRG_CK];
+            s = c.seed, l = c.lcg, h = c.hash;
+        }
+        for (u32 i = 0; i < (u32)(t % PRG_CK); i++) prv_step(s, l, h);
+    }
+    __device__ u64 next() { return prv_step(s, l, h); }
+};
+struct BiSenderArgs {
+    const PrgCk *ckCa, *ckCb, *ckW1, *ckW2, *ckWs; // checkpoint tables of the five stream sections
+    u64 tCa, tCb, tW1, tW2, tWs;                   // stream word of element 0 of the call in each section
+    const u64 *A0, *A1;                            // a = A0 (+ A1 when non-null)
+    const i8 *Bx, *By, *sel;                       // b_x ^ b_y picks the message, sel the helper word
+    u64 *d1a, *d1b, *d2a, *d2b, *ds;               // outputs, n words each
+    u64 n;
+    int aligned; // every input array is 16-byte aligned
+};
+// The whole "before the round" segment of an OT sender of bit_inject (party 0: ABY3Engine.cpp:539-620, party 1:
+// :709-790) in one pass, with nothing staged in memory.  For element e:
+//     M_t = (t ^ b_x ^ b_y) a - (Ca[e] + Cb[e])                      t = 0, 1          (:547-548, :751-752)
+//     d1a[e] = M_0 ^ W1_0[e], d1b[e] = M_1 ^ W1_1[e]     masked for the receiver, pair words of the helper's stream
+//     d2a[e] = M_0 ^ W2_0[e], d2b[e] = M_1 ^ W2_1[e]     the same messages under the other OT's pair words
+//     ds[e]  = Ws_{sel[e] == 1}[e]                       the word this party sends as the helper of the other OT
+// A lane owns 64 consecutive elements and five generators (the two C sections advance one word per element, the
+// three pair sections two), works through them in windows of 16 elements -- operands and bits are read from the
+// lane's own contiguous 128 / 16 bytes -- and hands each output array of a window to the wavefront through LDS, which
+// stores it in memory order (128-byte runs), as the other regenerating kernels do.
+__global__ __launch_bounds__(256) void bi_sender_pre_kernel(BiSenderArgs P) {
+    constexpr u32 EPL = 64, WIN = 16, PITCH = 2 * WIN + 1; // a row of the tile: one window of two output arrays
+    __shared__ u64 tile[256 * PITCH];
+    const u32 tid = threadIdx.x;
+    const u64 lane0 = (u64)blockIdx.x * 256; // first lane of the workgroup in the launch
+    const u64 e0 = (lane0 + tid) * EPL;
+    const bool active = e0 < P.n;
+    BiGen ca, cb, w1, w2, ws;
+    ca.open(P.ckCa, P.tCa + e0, active);
+    cb.open(P.ckCb, P.tCb + e0, active);
+    w1.open(P.ckW1, P.tW1 + 2 * e0, active);
+    w2.open(P.ckW2, P.tW2 + 2 * e0, active);
+    ws.open(P.ckWs, P.tWs + 2 * e0, active);
+    u64 *row_tile = tile + tid * PITCH;
+    // the wavefront stores half `h` of its lanes' rows of the tile at dst[element]
+    auto flush = [&](u64 *__restrict__ dst, u32 win, u32 h) {
+#pragma unroll 4
+        for (u32 j = 0; j < WIN; j++) {
+            const u32 idx = j * 64 + (tid & 63);
+            const u32 row = (tid & ~63u) + idx / WIN, col = idx % WIN;
+            const u64 e = (lane0 + row) * EPL + win * WIN + col;
+            if (e < P.n) dst[e] = tile[row * PITCH + h * WIN + col];
+        }
+    };
+#pragma unroll 1
+    for (u32 win = 0; win < EPL / WIN; win++) {
+        const u64 eb = e0 + win * WIN;
+        u64 m0[WIN], m1[WIN];
+        u32 selbits = 0;
+        if (P.aligned && eb + WIN <= P.n) { // the lane's 16 operands and bits are contiguous: 128 + 16 + 16 (+ 16) bytes
+            const uint4 bx = *(const uint4 *)(P.Bx + eb), by = *(const uint4 *)(P.By + eb), sl = *(const uint4 *)(P.sel + eb);
+            const u32 bxw[4] = {bx.x, bx.y, bx.z, bx.w}, byw[4] = {by.x, by.y, by.z, by.w}, slw[4] = {sl.x, sl.y, sl.z, sl.w};
+#pragma unroll
+            for (u32 q = 0; q < 4; q++) {
+                const ulonglong2 a01 = *(const ulonglong2 *)(P.A0 + eb + 4 * q), a23 = *(const ulonglong2 *)(P.A0 + eb + 4 * q + 2);
+                u64 a[4] = {a01.x, a01.y, a23.x, a23.y};
+                if (P.A1) {
+                    const ulonglong2 c01 = *(const ulonglong2 *)(P.A1 + eb + 4 * q), c23 = *(const ulonglong2 *)(P.A1 + eb + 4 * q + 2);
+                    a[0] += c01.x, a[1] += c01.y, a[2] += c23.x, a[3] += c23.y;
+                }
+#pragma unroll
+                for (u32 e = 0; e < 4; e++) {
+                    const u32 k = 4 * q + e;
+                    const i64 t = (i64)(i8)(((bxw[q] ^ byw[q]) >> (8 * e)) & 0xFF);
+                    selbits |= (u32)(((slw[q] >> (8 * e)) & 0xFF) == 1) << k;
+                    m0[k] = (u64)(0 ^ t) * a[e];
+                    m1[k] = (u64)(1 ^ t) * a[e];
+                }
+            }
+        } else {
+#pragma unroll
+            for (u32 k = 0; k < WIN; k++) {
+                u64 a = 0;
+                i64 t = 0;
+                if (eb + k < P.n) {
+                    a = P.A0[eb + k];
+                    if (P.A1) a += P.A1[eb + k];
+                    t = (i64)(i8)(P.Bx[eb + k] ^ P.By[eb + k]);
+                    selbits |= (u32)(P.sel[eb + k] == 1) << k;
+                }
+                m0[k] = (u64)(0 ^ t) * a;
+                m1[k] = (u64)(1 ^ t) * a;
+            }
+        }
+#pragma unroll
+        for (u32 k = 0; k < WIN; k++) {
+            const u64 cc = ca.next() + cb.next();
+            m0[k] -= cc;
+            m1[k] -= cc;
+        }
+        // The sections' generators are independent of one another: the fences keep the scheduler from running them
+        // side by side and holding all their words in registers.
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (u32 k = 0; k < WIN; k++) {
+            row_tile[k] = m0[k] ^ w1.next();
+            row_tile[WIN + k] = m1[k] ^ w1.next();
+        }
+        prg_wave_sync();
+        flush(P.d1a, win, 0);
+        flush(P.d1b, win, 1);
+        prg_wave_sync();
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (u32 k = 0; k < WIN; k++) {
+            row_tile[k] = m0[k] ^ w2.next();
+            row_tile[WIN + k] = m1[k] ^ w2.next();
+        }
+        prg_wave_sync();
+        flush(P.d2a, win, 0);
+        flush(P.d2b, win, 1);
+        prg_wave_sync();
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (u32 k = 0; k < WIN; k++) {
+            const u64 x0 = ws.next(), x1 = ws.next();
+            row_tile[k] = ((selbits >> k) & 1) ? x1 : x0;
+        }
+        prg_wave_sync();
+        flush(P.ds, win, 0);
+        prg_wave_sync();
+        __builtin_amdgcn_sched_barrier(0);
+    }
 }
-// out[e] = W_b[e] with b = (sel[e] == 1): the helper's word for the receiver
-int bi_select_pairs(mpcx_ctx *ctx, u64 seed, u64 t_first, u64 n, const i8 *sel, u64 *out) {
-    return prg_map1(ctx, seed, t_first, 2 * n, [=] __device__(u64 w, u64 v) {
-        const u64 e = w >> 1;
-        if ((u64)(sel[e] == 1) == (w & 1)) out[e] = v;
-    });
+
+// The helper's segment before the round (party 2, ABY3Engine.cpp:875-922): da[e] = Wa_{sa[e] == 1}[e] and
+// db[e] = Wb_{sb[e] == 1}[e] for the pair sections of two streams, in one pass with the geometry of
+// bi_sender_pre_kernel (a lane owns 64 elements, windows of 16, stores in memory order through LDS).
+struct BiHelperArgs {
+    const PrgCk *ckWa, *ckWb;
+    u64 tWa, tWb;
+    const i8 *sa, *sb;
+    u64 *da, *db;
+    u64 n;
+};
+__global__ __launch_bounds__(256) void bi_helper_pre_kernel(BiHelperArgs P) {
+    constexpr u32 EPL = 64, WIN = 16, PITCH = 2 * WIN + 1;
+    __shared__ u64 tile[256 * PITCH];
+    const u32 tid = threadIdx.x;
+    const u64 lane0 = (u64)blockIdx.x * 256;
+    const u64 e0 = (lane0 + tid) * EPL;
+    const bool active = e0 < P.n;
+    BiGen wa, wb;
+    wa.open(P.ckWa, P.tWa + 2 * e0, active);
+    wb.open(P.ckWb, P.tWb + 2 * e0, active);
+    u64 *row_tile = tile + tid * PITCH;
+#pragma unroll 1
+    for (u32 win = 0; win < EPL / WIN; win++) {
+        const u64 eb = e0 + win * WIN;
+        u32 abits = 0, bbits = 0;
+#pragma unroll
+        for (u32 k = 0; k < WIN; k++)
+            if (eb + k < P.n) {
+                abits |= (u32)(P.sa[eb + k] == 1) << k;
+                bbits |= (u32)(P.sb[eb + k] == 1) << k;
+            }
+#pragma unroll
+        for (u32 k = 0; k < WIN; k++) {
+            const u64 a0 = wa.next(), a1 = wa.next(), b0 = wb.next(), b1 = wb.next();
+            row_tile[k] = ((abits >> k) & 1) ? a1 : a0;
+            row_tile[WIN + k] = ((bbits >> k) & 1) ? b1 : b0;
+        }
+        prg_wave_sync();
+#pragma unroll
+        for (u32 h = 0; h < 2; h++) {
+            u64 *__restrict__ dst = h ? P.db : P.da;
+#pragma unroll 4
+            for (u32 j = 0; j < WIN; j++) {
+                const u32 idx = j * 64 + (tid & 63);
+                const u32 row = (tid & ~63u) + idx / WIN, col = idx % WIN;
+                const u64 e = (lane0 + row) * EPL + win * WIN + col;
+                if (e < P.n) dst[e] = tile[row * PITCH + h * WIN + col];
+            }
+        }
+        prg_wave_sync();
+    }
+}
+
+int bi_sender_launch(mpcx_ctx *ctx, BiSenderArgs P) {
+    P.aligned = (((uintptr_t)P.A0 | (uintptr_t)P.A1 | (uintptr_t)P.Bx | (uintptr_t)P.By | (uintptr_t)P.sel) & 15) == 0;
+    const u64 grid = ceil_div(ceil_div(P.n, 64), 256);
+    MPCX_REQUIRE(grid < (1ull << 31), "bit_inject: range too large for one launch");
+    ProfScope ps(ctx, PROF_PRG);
+    hipLaunchKernelGGL(bi_sender_pre_kernel, dim3((u32)grid), dim3(256), 0, ctx->stream, P);
+    MPCX_LAUNCH_CHECK();
+    return 0;
 }
 } // namespace
 #define BI_RANGE_CHECK(name)                                                                                           \
@@ -393,20 +768,20 @@ int mpcx_aby3_bit_inject_p0_pre(mpcx_ctx *ctx, const int64_t *A0, const int8_t *
     MPCX_REQUIRE(A0 && B0 && B1 && to_p1 && to_p2, "mpcx_aby3_bit_inject_p0_pre: NULL pointer");
     const BiGeom G{n_total, i0, n};
     const u64 b01 = PRG_POP_T0 + pop01, b20 = PRG_POP_T0 + pop20;
-    void *ws;
-    MPCX_TRY(mpcx_ws(ctx, 16 * n, &ws));
-    u64 *M = (u64 *)ws;
-    // M_t = (t ^ b_x ^ b_y) a - c - c' with c + c' = C01 + C02 (ABY3Engine.cpp:547-548)
-    MPCX_TRY(prg_map2(ctx, seed01, G.c(b01), seed20, G.c(b20), n, [] __device__(u64 a, u64 b) { return a + b; },
-                      [=] __device__(u64 i, u64 cc) {
-                          const u64 a = (u64)A0[i];
-                          const i64 t = (i64)(B0[i] ^ B1[i]);
-                          M[i] = (u64)(0 ^ t) * a - cc;
-                          M[n + i] = (u64)(1 ^ t) * a - cc;
-                      }));
-    MPCX_TRY(bi_mask_pairs(ctx, seed20, G.w(b20), n, M, (u64 *)to_p1));                  // ^ W02
-    MPCX_TRY(bi_mask_pairs(ctx, seed01, G.w(b01), n, M, (u64 *)to_p2));                  // ^ W01
-    return bi_select_pairs(ctx, seed01, G.w(b01 + 3 * n_total), n, B0, (u64 *)to_p2 + 2 * n); // W10_b (:603)
+    const PrgCk *ck01, *ck20;
+    MPCX_TRY(mpcx_prg_table(ctx, seed01, 0, b01 + 6 * n_total, &ck01));
+    MPCX_TRY(mpcx_prg_table(ctx, seed20, 0, b20 + 3 * n_total, &ck20));
+    BiSenderArgs P;
+    P.ckCa = ck01, P.tCa = G.c(b01);                               // C01
+    P.ckCb = ck20, P.tCb = G.c(b20);                               // C02
+    P.ckW1 = ck20, P.tW1 = G.w(b20);                               // W02: the messages for party 1 (:590-599)
+    P.ckW2 = ck01, P.tW2 = G.w(b01);                               // W01: the same messages for party 2
+    P.ckWs = ck01, P.tWs = G.w(b01 + 3 * n_total);                 // W10_b (:603)
+    P.A0 = (const u64 *)A0, P.A1 = nullptr, P.Bx = B0, P.By = B1, P.sel = B0;
+    P.d1a = (u64 *)to_p1, P.d1b = (u64 *)to_p1 + n;
+    P.d2a = (u64 *)to_p2, P.d2b = (u64 *)to_p2 + n, P.ds = (u64 *)to_p2 + 2 * n;
+    P.n = n;
+    return bi_sender_launch(ctx, P);
 }
 int mpcx_aby3_bit_inject_p0_post(mpcx_ctx *ctx, const int8_t *B0, uint64_t n_total, uint64_t i0, uint64_t n,
                                  uint64_t seed01, uint64_t pop01, uint64_t seed20, uint64_t pop20,
@@ -433,20 +808,20 @@ int mpcx_aby3_bit_inject_p1_pre(mpcx_ctx *ctx, const int64_t *A0, const int64_t 
     MPCX_REQUIRE(A0 && A1 && B0 && B1 && to_p0 && to_p2, "mpcx_aby3_bit_inject_p1_pre: NULL pointer");
     const BiGeom G{n_total, i0, n};
     const u64 b01 = PRG_POP_T0 + pop01, b12 = PRG_POP_T0 + pop12;
-    void *ws;
-    MPCX_TRY(mpcx_ws(ctx, 16 * n, &ws));
-    u64 *M = (u64 *)ws;
-    // M_t = (t ^ b_x ^ b_y)(a_1 + a_2) - C10 - C12 (:751-752)
-    MPCX_TRY(prg_map2(ctx, seed01, G.c(b01 + 3 * n_total), seed12, G.c(b12), n, [] __device__(u64 a, u64 b) { return a + b; },
-                      [=] __device__(u64 i, u64 cc) {
-                          const u64 a = (u64)A0[i] + (u64)A1[i];
-                          const i64 t = (i64)(B0[i] ^ B1[i]);
-                          M[i] = (u64)(0 ^ t) * a - cc;
-                          M[n + i] = (u64)(1 ^ t) * a - cc;
-                      }));
-    MPCX_TRY(bi_select_pairs(ctx, seed01, G.w(b01), n, B1, (u64 *)to_p2));                        // W01_b (:722)
-    MPCX_TRY(bi_mask_pairs(ctx, seed01, G.w(b01 + 3 * n_total), n, M, (u64 *)to_p2 + n));         // ^ W10
-    return bi_mask_pairs(ctx, seed12, G.w(b12), n, M, (u64 *)to_p0);                              // ^ W12
+    const PrgCk *ck01, *ck12;
+    MPCX_TRY(mpcx_prg_table(ctx, seed01, 0, b01 + 6 * n_total, &ck01));
+    MPCX_TRY(mpcx_prg_table(ctx, seed12, 0, b12 + 3 * n_total, &ck12));
+    BiSenderArgs P;
+    P.ckCa = ck01, P.tCa = G.c(b01 + 3 * n_total);                 // C10
+    P.ckCb = ck12, P.tCb = G.c(b12);                               // C12
+    P.ckW1 = ck12, P.tW1 = G.w(b12);                               // W12: the messages for party 0 (:743-761)
+    P.ckW2 = ck01, P.tW2 = G.w(b01 + 3 * n_total);                 // W10: the same messages for party 2
+    P.ckWs = ck01, P.tWs = G.w(b01);                               // W01_b (:722)
+    P.A0 = (const u64 *)A0, P.A1 = (const u64 *)A1, P.Bx = B0, P.By = B1, P.sel = B1;
+    P.d1a = (u64 *)to_p0, P.d1b = (u64 *)to_p0 + n;
+    P.d2a = (u64 *)to_p2 + n, P.d2b = (u64 *)to_p2 + 2 * n, P.ds = (u64 *)to_p2;
+    P.n = n;
+    return bi_sender_launch(ctx, P);
 }
 int mpcx_aby3_bit_inject_p1_post(mpcx_ctx *ctx, const int8_t *B1, uint64_t n_total, uint64_t i0, uint64_t n,
                                  uint64_t seed01, uint64_t pop01, uint64_t seed12, uint64_t pop12,
@@ -472,8 +847,18 @@ int mpcx_aby3_bit_inject_p2_pre(mpcx_ctx *ctx, const int8_t *B0, const int8_t *B
     if (n == 0) return 0;
     MPCX_REQUIRE(B0 && B1 && to_p0 && to_p1, "mpcx_aby3_bit_inject_p2_pre: NULL pointer");
     const BiGeom G{n_total, i0, n};
-    MPCX_TRY(bi_select_pairs(ctx, seed20, G.w(PRG_POP_T0 + pop20), n, B0, (u64 *)to_p1)); // W02_b (:888)
-    return bi_select_pairs(ctx, seed12, G.w(PRG_POP_T0 + pop12), n, B1, (u64 *)to_p0);    // W12_b (:922)
+    BiHelperArgs P;
+    MPCX_TRY(mpcx_prg_table(ctx, seed20, 0, PRG_POP_T0 + pop20 + 3 * n_total, &P.ckWa));
+    MPCX_TRY(mpcx_prg_table(ctx, seed12, 0, PRG_POP_T0 + pop12 + 3 * n_total, &P.ckWb));
+    P.tWa = G.w(PRG_POP_T0 + pop20), P.sa = B0, P.da = (u64 *)to_p1; // W02_b (:888)
+    P.tWb = G.w(PRG_POP_T0 + pop12), P.sb = B1, P.db = (u64 *)to_p0; // W12_b (:922)
+    P.n = n;
+    const u64 grid = ceil_div(ceil_div(n, 64), 256);
+    MPCX_REQUIRE(grid < (1ull << 31), "bit_inject: range too large for one launch");
+    ProfScope ps(ctx, PROF_PRG);
+    hipLaunchKernelGGL(bi_helper_pre_kernel, dim3((u32)grid), dim3(256), 0, ctx->stream, P);
+    MPCX_LAUNCH_CHECK();
+    return 0;
 }
 int mpcx_aby3_bit_inject_p2_post(mpcx_ctx *ctx, const int8_t *B0, const int8_t *B1, uint64_t n_total, uint64_t i0,
                                  uint64_t n, uint64_t seed20, uint64_t pop20, uint64_t seed12, uint64_t pop12,

@@ -1,6 +1,7 @@
 // Internal declarations shared by the HIP translation units of libmpcx (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <array>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -55,6 +56,8 @@ struct mpcx_ctx {
     u64 rand_bytes = 0, rand_cap = 4ull << 30, rand_tick = 0;
     // mpcx_malloc / mpcx_free recycle device blocks: every use of a block is ordered on the context's stream,
     // so a freed block can be handed out again without waiting for the kernels that still read it.
+    // mpcx_aby3_msb_begin: the G0, G1, P0, P1 arrays that the first round of a carry tree reads in place, per state buffer
+    std::map<const void *, std::array<const i64 *, 4>> msb_inputs;
     std::multimap<u64, void *> pool_free; // idle blocks by size
     std::map<void *, u64> pool_live;      // blocks handed out -> size
     u64 pool_idle_bytes = 0, pool_cap = 8ull << 30;

@@ -270,20 +270,22 @@ void ABY3Engine::msb(const array<VecI64, 2> &Gj, const array<VecI64, 2> &Pj, arr
     Dev<uint64_t> state(gpu, 6 * n);
     Dev<int64_t> g0(gpu, Gj[0].data(), n), g1(gpu, Gj[1].data(), n); // read in place by the first round
     GPU_OK(gpu, mpcx_aby3_msb_begin(gpu, g0, g1, p0, p1, n, state));
-    Dev<int8_t> msg(gpu, 64 * n);
+    // one device call per local segment: the first message, then for every received message the next one, then Z
+    Dev<int8_t> msg_in(gpu, 64 * n), msg_out(gpu, 64 * n), z0(gpu, n), z1(gpu, n);
+    GPU_OK(gpu, mpcx_aby3_msb_round_pre(gpu, state, n, 32, msg_out));
     for (size_t temp = 32; temp != 0; temp /= 2) {
         const size_t bytes = 2 * temp * n;
-        GPU_OK(gpu, mpcx_aby3_msb_round_pre(gpu, state, n, temp, msg));
         message_send[pe.next].clear();
         message_send[pe.prev].resize(bytes);
-        if (bytes) msg.down(&message_send[pe.prev][0], bytes);
+        if (bytes) msg_out.down(&message_send[pe.prev][0], bytes);
         messenger->send_and_recv(message_send, message_recv);
         MSG_CHECK(message_recv[pe.next].size() == bytes);
-        upload_string(msg, message_recv[pe.next]);
-        GPU_OK(gpu, mpcx_aby3_msb_round_post(gpu, state, n, temp, msg));
+        upload_string(msg_in, message_recv[pe.next]);
+        if (temp != 1)
+            GPU_OK(gpu, mpcx_aby3_msb_round_mid(gpu, state, n, temp, msg_in, msg_out));
+        else
+            GPU_OK(gpu, mpcx_aby3_msb_last(gpu, state, n, msg_in, z0, z1));
     }
-    Dev<int8_t> z0(gpu, n), z1(gpu, n);
-    GPU_OK(gpu, mpcx_aby3_msb_final(gpu, state, p0, p1, n, z0, z1));
     Zj[0].resize(n);
     Zj[1].resize(n);
     z0.down(Zj[0].data(), n);

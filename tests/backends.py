@@ -460,6 +460,24 @@ class GpuBackend:
             self.ctx.sync()
             return Z0.to_host(), Z1.to_host()
 
+        def _skewed(self, host):
+            k = GpuBackend.msb_msg_skew
+            buf = self.ctx.to_device(np.concatenate([np.zeros(k, np.int8), np.asarray(host, np.int8)]), np.int8)
+            return buf.view(k, host.size)
+
+        def round_mid(self, temp, msg_in):
+            k = GpuBackend.msb_msg_skew
+            out = self.ctx.empty(np.int8, self.n * temp + k).view(k, self.n * temp)
+            self.ctx.call("aby3_msb_round_mid", self.state, self.n, temp, self._skewed(msg_in), out)
+            self.ctx.sync()
+            return out.to_host()
+
+        def last(self, msg_in):
+            Z0, Z1 = self.ctx.empty(np.int8, self.n), self.ctx.empty(np.int8, self.n)
+            self.ctx.call("aby3_msb_last", self.state, self.n, self._skewed(msg_in), Z0, Z1)
+            self.ctx.sync()
+            return Z0.to_host(), Z1.to_host()
+
     def aby3_msb_begin(self, G0, G1, P0, P1):
         return GpuBackend._Msb(self.ctx, G0, G1, P0, P1)
 
@@ -688,6 +706,16 @@ class ResidentBackend(GpuBackend):
         def final(self):
             Z0, Z1 = self.be.empty(np.int8, self.n), self.be.empty(np.int8, self.n)
             self.be._run("aby3_msb_final", self.state, self.P0, self.P1, self.n, Z0, Z1)
+            return Z0, Z1
+
+        def round_mid(self, temp, msg_in):
+            msg = self.be.empty(np.int8, self.n * temp)
+            self.be._run("aby3_msb_round_mid", self.state, self.n, temp, msg_in, msg)
+            return msg
+
+        def last(self, msg_in):
+            Z0, Z1 = self.be.empty(np.int8, self.n), self.be.empty(np.int8, self.n)
+            self.be._run("aby3_msb_last", self.state, self.n, msg_in, Z0, Z1)
             return Z0, Z1
 
     def aby3_msb_begin(self, G0, G1, P0, P1):

@@ -112,9 +112,22 @@ def aby3_add_prepare(w, Xs):
     return Gs, Ps
 
 
+MSB_FUSED = True  # drive backends that have them through round_mid / last (one call per messenger gap)
+
+
 def aby3_msb(w, Gs, Ps):
     """msb (ABY3Engine.cpp:361-467): six rounds temp = 32..1, message 2*temp bytes per element to prev."""
     hs = [w.be.aby3_msb_begin(Gs[j][0], Gs[j][1], Ps[j][0], Ps[j][1]) for j in range(3)]
+    if MSB_FUSED and hasattr(hs[0], "round_mid"):
+        msgs = [hs[j].round_pre(32) for j in range(3)]
+        temp = 32
+        while True:
+            for j in range(3):
+                w.rec(f"msb.t{temp}.P{j}", msgs[j])
+            if temp == 1:
+                return [hs[j].last(msgs[(j + 1) % 3]) for j in range(3)]
+            msgs = [hs[j].round_mid(temp, msgs[(j + 1) % 3]) for j in range(3)]
+            temp //= 2
     temp = 32
     while temp:
         msgs = [hs[j].round_pre(temp) for j in range(3)]

@@ -170,9 +170,11 @@ def test_aby3_matmul_row_blocks_equal_whole(gpu, orc):
     assert np.array_equal(np.concatenate(parts), whole)
 
 
-@pytest.mark.parametrize("n", [1, 4, 63, 1000, 4097, (1 << 20) + 4099])  # the last: every kernel grid-strides
-def test_aby3_relu_chain_parity(gpu, orc, n):
+@pytest.mark.parametrize("fused", [True, False])  # msb as one call per messenger gap, or as separate post / pre calls
+@pytest.mark.parametrize("n", [1, 4, 63, 64, 65, 1000, 4097, (1 << 20) + 4099])  # the last: every kernel grid-strides
+def test_aby3_relu_chain_parity(gpu, orc, n, fused, monkeypatch):
     """share -> add_prepare -> msb -> bit_inject: every message and every share equals the oracle's."""
+    monkeypatch.setattr(pr, "MSB_FUSED", fused)
     X = prg_pops(21, 0, n)
     X[: min(n, 6)] = np.array([0, -1, 1, -2 ** 63, 2 ** 63 - 1, -2], dtype=np.int64)[: min(n, 6)]
     res = []
@@ -238,6 +240,28 @@ def test_aby3_vecbool_mul_and_reveal_bits_parity(gpu, orc, n):
     assert np.array_equal(got, orc.aby3_reveal3_bits(a, b, c)) and np.array_equal(got, a ^ b ^ c)
 
 
+@pytest.mark.parametrize("n", [1, 15, 16, 17, 64, 1000, 70001])
+def test_bit_inject_senders_with_unaligned_inputs(gpu, orc, n):
+    """The OT senders' segments (parties 0 and 1, before the round) on operands that start 8 bytes (words) and 3 bytes
+    (booleans) into their allocations, and on booleans that are not 0 / 1: the messages equal the oracle's."""
+    ctx = gpu.ctx
+    rng = np.random.default_rng(n)
+    A0, A1 = rnd(rng, n), rnd(rng, n)
+    for wild in (False, True):
+        B0, B1 = (rng.integers(-128, 128, n, dtype=np.int8) if wild else rng.integers(0, 2, n, dtype=np.int8) for _ in range(2))
+        dA0, dA1 = (ctx.to_device(np.concatenate([np.zeros(1, np.int64), a])).view(1, n) for a in (A0, A1))
+        dB0, dB1 = (ctx.to_device(np.concatenate([np.zeros(3, np.int8), b])).view(3, n) for b in (B0, B1))
+        o1, o2 = ctx.empty(np.int64, 2 * n + 1).view(1, 2 * n), ctx.empty(np.int64, 3 * n)
+        ctx.call("aby3_bit_inject_p0_pre", dA0, dB0, dB1, n, 0, n, KEY01, 7, KEY20, 130, o1, o2)
+        ctx.sync()
+        w1, w2 = orc.aby3_bit_inject_p0_pre(A0, B0, B1, KEY01, 7, KEY20, 130)
+        assert np.array_equal(o1.to_host(), w1) and np.array_equal(o2.to_host(), w2)
+        ctx.call("aby3_bit_inject_p1_pre", dA0, dA1, dB0, dB1, n, 0, n, KEY01, 7, KEY12, 64, o1, o2)
+        ctx.sync()
+        w1, w2 = orc.aby3_bit_inject_p1_pre(A0, A1, B0, B1, KEY01, 7, KEY12, 64)
+        assert np.array_equal(o1.to_host(), w1) and np.array_equal(o2.to_host(), w2)
+
+
 def test_empty_inputs_are_noops(gpu):
     e = np.zeros(0, dtype=np.int64)
     assert gpu.ring_add(e, e).size == 0
@@ -257,7 +281,7 @@ def test_bad_shapes_are_rejected(gpu):
         gpu.aby3_bit_inject_p2_pre(b, b, KEY20, 0, KEY12, 0, rng=(10, 8))
 
 
-@pytest.mark.parametrize("n", [1, 3, 13, 777])
+@pytest.mark.parametrize("n", [1, 3, 13, 777, 5001])
 def test_aby3_msb_messages_at_8_byte_alignment(gpu, orc, n, monkeypatch):
     """msb round messages that are 8- but not 16-byte aligned take the kernels' narrower load / store path."""
     from backends import GpuBackend
