@@ -51,6 +51,12 @@ int mpcx_set_pool_limit(mpcx_ctx *ctx, uint64_t max_idle_bytes);
 int mpcx_h2d(mpcx_ctx *ctx, void *dst, const void *src, uint64_t bytes);
 int mpcx_d2h(mpcx_ctx *ctx, void *dst, const void *src, uint64_t bytes);
 int mpcx_d2d(mpcx_ctx *ctx, void *dst, const void *src, uint64_t bytes);
+/* mpcx_h2d / mpcx_d2h return when the copy is complete; host memory may be pageable (the std::string payloads of
+ * VirtuleMessenger::send_and_recv, utils/VirtuleMessenger.hpp:14).  Transfers of 4 MiB and more are pipelined through
+ * two pinned staging buffers of the context, DMA on one chunk while host threads (MPCX_COPY_THREADS, default 4) copy
+ * the other.  mpcx_host_copy is that multi-threaded memcpy by itself, for messengers that move payloads between
+ * host buffers (utils/SocketMessenger.cpp:142-164 does it through the kernel's socket buffers). */
+int mpcx_host_copy(void *dst, const void *src, uint64_t bytes);
 /* per-kernel device timing with HIP events recorded on the context's stream: mpcx_profile(ctx,1) starts
  * (and clears) the collection, mpcx_profile_read sums the elapsed time of every launch of one kernel
  * family since then: "limb_gemm", "split_limbs", "prg_fill", "pc_party", "pc_helper",

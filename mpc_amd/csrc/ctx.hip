@@ -1,8 +1,123 @@
 // Context, memory and error plumbing of libmpcx.
+#include <atomic>
+#include <chrono>
 #include <cstdarg>
+#include <cstring>
+#include <condition_variable>
+#include <deque>
+#include <functional>
 #include <mutex>
+#include <thread>
 
 #include "mpcx_internal.h"
+
+// ---- a small pool of host threads for copies between pageable and pinned memory.  One core copies ~12 GB/s; a
+// message of hundreds of megabytes has to move at the rate of the PCIe link (~55 GB/s), so large copies are cut into
+// pieces that several threads move at once.  The pool lives until the process ends (its objects are never destroyed,
+// so no thread can outlive them).
+namespace {
+struct CopyPool {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<std::function<void()>> jobs;
+    unsigned threads = 0;
+    CopyPool() {
+        const char *e = getenv("MPCX_COPY_THREADS");
+        long n = e ? atol(e) : 4;
+        threads = (unsigned)(n < 0 ? 0 : n > 32 ? 32 : n);
+        for (unsigned i = 0; i < threads; i++)
+            std::thread([this] {
+                for (;;) {
+                    std::function<void()> job;
+                    {
+                        std::unique_lock<std::mutex> lk(mu);
+                        cv.wait(lk, [&] { return !jobs.empty(); });
+                        job = std::move(jobs.front());
+                        jobs.pop_front();
+                    }
+                    job();
+                }
+            }).detach();
+    }
+};
+CopyPool &copy_pool() {
+    static CopyPool *p = new CopyPool(); // never destroyed
+    return *p;
+}
+} // namespace
+
+// MPCX_COPY_STATS=1: bytes and wall time spent in mpcx_h2d / mpcx_d2h / mpcx_host_copy, printed when the process ends
+namespace {
+struct CopyStats {
+    std::atomic<u64> bytes[3], ns[3], calls[3];
+    bool on;
+    CopyStats() {
+        const char *e = getenv("MPCX_COPY_STATS");
+        on = e && atoi(e) != 0;
+        for (int k = 0; k < 3; k++) bytes[k] = ns[k] = calls[k] = 0;
+        if (on) atexit([] {
+            static const char *names[3] = {"h2d", "d2h", "host_copy"};
+            CopyStats &S = copy_stats();
+            for (int k = 0; k < 3; k++)
+                fprintf(stderr, "[mpcx] %-9s %8llu calls %10.1f MB %9.2f ms (summed over threads) %7.2f GB/s\n", names[k],
+                        (unsigned long long)S.calls[k].load(), S.bytes[k].load() / 1e6, S.ns[k].load() / 1e6,
+                        S.ns[k].load() ? (double)S.bytes[k].load() / (double)S.ns[k].load() : 0.0);
+        });
+    }
+    static CopyStats &copy_stats() {
+        static CopyStats *s = new CopyStats();
+        return *s;
+    }
+};
+struct CopyTimer {
+    int slot;
+    u64 bytes;
+    std::chrono::steady_clock::time_point t0;
+    CopyTimer(int s, u64 b) : slot(s), bytes(b) {
+        if (CopyStats::copy_stats().on) t0 = std::chrono::steady_clock::now();
+    }
+    ~CopyTimer() {
+        CopyStats &S = CopyStats::copy_stats();
+        if (!S.on) return;
+        S.ns[slot] += (u64)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+        S.bytes[slot] += bytes;
+        S.calls[slot]++;
+    }
+};
+} // namespace
+
+void mpcx_parallel_memcpy(void *dst, const void *src, u64 bytes) {
+    CopyPool &P = copy_pool();
+    const u64 piece_min = 1ull << 20;
+    if (P.threads == 0 || bytes < 2 * piece_min) {
+        memcpy(dst, src, bytes);
+        return;
+    }
+    u64 pieces = bytes / piece_min;
+    if (pieces > P.threads + 1) pieces = P.threads + 1; // the caller copies a piece itself
+    const u64 per = ((bytes + pieces - 1) / pieces + 63) & ~63ull;
+    struct Latch {
+        std::mutex mu;
+        std::condition_variable cv;
+        u64 left;
+    } latch;
+    latch.left = pieces - 1;
+    {
+        std::lock_guard<std::mutex> lk(P.mu);
+        for (u64 k = 1; k < pieces; k++) {
+            const u64 off = k * per, len = off >= bytes ? 0 : (bytes - off < per ? bytes - off : per);
+            P.jobs.emplace_back([=, &latch] {
+                if (len) memcpy((char *)dst + off, (const char *)src + off, len);
+                std::lock_guard<std::mutex> g(latch.mu);
+                if (--latch.left == 0) latch.cv.notify_one();
+            });
+        }
+    }
+    P.cv.notify_all();
+    memcpy(dst, src, per < bytes ? per : bytes);
+    std::unique_lock<std::mutex> lk(latch.mu);
+    latch.cv.wait(lk, [&] { return latch.left == 0; });
+}
 
 static thread_local std::string g_init_err;
 
@@ -67,6 +182,7 @@ int mpcx_init(int device, mpcx_ctx **out) {
         delete ctx;
         return 1;
     }
+    prg_tables_context_opened(device);
     *out = ctx;
     return 0;
 }
@@ -76,6 +192,11 @@ int mpcx_shutdown(mpcx_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->ws) (void)hipFree(ctx->ws);
+    for (int k = 0; k < 2; k++)
+        if (ctx->stage[k]) {
+            (void)hipHostFree(ctx->stage[k]);
+            (void)hipEventDestroy(ctx->stage_ev[k]);
+        }
     prg_rand_cache_clear(ctx);
     for (auto &b : ctx->pool_free) (void)hipFree(b.second);
     for (auto &b : ctx->pool_live) (void)hipFree(b.first);
@@ -85,6 +206,7 @@ int mpcx_shutdown(mpcx_ctx *ctx) {
             (void)hipEventDestroy(p.second);
         }
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    prg_tables_context_closed(ctx->device);
     delete ctx;
     return 0;
 }
@@ -160,9 +282,44 @@ int mpcx_set_pool_limit(mpcx_ctx *ctx, uint64_t max_idle_bytes) {
     if (ctx->pool_idle_bytes > max_idle_bytes) return pool_drain(ctx);
     return 0;
 }
+// Large transfers between the device and pageable host memory (the std::string payloads of the messenger) go through
+// two pinned staging buffers of the context: the DMA engine moves one chunk while host threads copy the previous one
+// between its staging buffer and the caller's memory, so the transfer runs at the rate of the slower of the two
+// instead of at the single-threaded rate of a pageable hipMemcpy.  MPCX_STAGED_COPY=0 restores the plain path.
+static const u64 kStageChunk = 4ull << 20, kStageMin = 4ull << 20;
+static bool staged_copies() {
+    static const bool on = [] {
+        const char *e = getenv("MPCX_STAGED_COPY");
+        return !(e && atoi(e) == 0);
+    }();
+    return on;
+}
+static int stage_setup(mpcx_ctx *ctx) {
+    if (ctx->stage[0]) return 0;
+    MPCX_HIP(hipSetDevice(ctx->device));
+    for (int k = 0; k < 2; k++) {
+        MPCX_HIP(hipHostMalloc(&ctx->stage[k], kStageChunk, hipHostMallocDefault));
+        MPCX_HIP(hipEventCreateWithFlags(&ctx->stage_ev[k], hipEventDisableTiming));
+    }
+    return 0;
+}
 int mpcx_h2d(mpcx_ctx *ctx, void *dst, const void *src, uint64_t bytes) {
     MPCX_REQUIRE(ctx, "mpcx_h2d: the context is NULL (already shut down?)");
     if (!bytes) return 0;
+    CopyTimer timer(0, bytes);
+    if (bytes >= kStageMin && staged_copies()) {
+        MPCX_TRY(stage_setup(ctx));
+        u64 k = 0;
+        for (u64 off = 0; off < bytes; off += kStageChunk, k++) {
+            const u64 len = bytes - off < kStageChunk ? bytes - off : kStageChunk;
+            if (k >= 2) MPCX_HIP(hipEventSynchronize(ctx->stage_ev[k & 1])); // its previous chunk has left the buffer
+            mpcx_parallel_memcpy(ctx->stage[k & 1], (const char *)src + off, len);
+            MPCX_HIP(hipMemcpyAsync((char *)dst + off, ctx->stage[k & 1], len, hipMemcpyHostToDevice, ctx->stream));
+            MPCX_HIP(hipEventRecord(ctx->stage_ev[k & 1], ctx->stream));
+        }
+        MPCX_HIP(hipStreamSynchronize(ctx->stream)); // the staging buffers are free again when the call returns
+        return 0;
+    }
     MPCX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
     MPCX_HIP(hipStreamSynchronize(ctx->stream)); // the host buffer may be pageable and reused at once
     return 0;
@@ -170,8 +327,32 @@ int mpcx_h2d(mpcx_ctx *ctx, void *dst, const void *src, uint64_t bytes) {
 int mpcx_d2h(mpcx_ctx *ctx, void *dst, const void *src, uint64_t bytes) {
     MPCX_REQUIRE(ctx, "mpcx_d2h: the context is NULL (already shut down?)");
     if (!bytes) return 0;
+    CopyTimer timer(1, bytes);
+    if (bytes >= kStageMin && staged_copies()) {
+        MPCX_TRY(stage_setup(ctx));
+        const u64 chunks = (bytes + kStageChunk - 1) / kStageChunk;
+        auto issue = [&](u64 k) -> int {
+            const u64 off = k * kStageChunk, len = bytes - off < kStageChunk ? bytes - off : kStageChunk;
+            MPCX_HIP(hipMemcpyAsync(ctx->stage[k & 1], (const char *)src + off, len, hipMemcpyDeviceToHost, ctx->stream));
+            MPCX_HIP(hipEventRecord(ctx->stage_ev[k & 1], ctx->stream));
+            return 0;
+        };
+        MPCX_TRY(issue(0));
+        for (u64 k = 0; k < chunks; k++) {
+            if (k + 1 < chunks) MPCX_TRY(issue(k + 1)); // into the other buffer, emptied in the previous iteration
+            MPCX_HIP(hipEventSynchronize(ctx->stage_ev[k & 1]));
+            const u64 off = k * kStageChunk, len = bytes - off < kStageChunk ? bytes - off : kStageChunk;
+            mpcx_parallel_memcpy((char *)dst + off, ctx->stage[k & 1], len);
+        }
+        return 0;
+    }
     MPCX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     MPCX_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+int mpcx_host_copy(void *dst, const void *src, uint64_t bytes) {
+    CopyTimer timer(2, bytes);
+    if (bytes) mpcx_parallel_memcpy(dst, src, bytes);
     return 0;
 }
 int mpcx_d2d(mpcx_ctx *ctx, void *dst, const void *src, uint64_t bytes) {

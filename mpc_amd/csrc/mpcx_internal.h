@@ -41,6 +41,8 @@ struct mpcx_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     std::string err;
+    void *stage[2] = {nullptr, nullptr}; // pinned staging buffers of the large host <-> device copies
+    hipEvent_t stage_ev[2] = {nullptr, nullptr};
     void *ws = nullptr; // scratch workspace, grown on demand
     u64 ws_bytes = 0;
     // Values derived from a generator's int_buff, kept on the device between calls.  The reference fills
@@ -64,6 +66,8 @@ struct mpcx_ctx {
 };
 
 int mpcx_fail(mpcx_ctx *ctx, const char *fmt, ...);
+// memcpy cut into pieces moved by the library's pool of host threads (MPCX_COPY_THREADS, default 4) and the caller
+void mpcx_parallel_memcpy(void *dst, const void *src, u64 bytes);
 // scratch of at least `bytes`, 256-byte aligned, valid until the next mpcx_ws call on this context
 int mpcx_ws(mpcx_ctx *ctx, u64 bytes, void **out);
 // device pointer to the checkpoint table of (seed,lcg) covering stream words [0, t_end)
@@ -122,6 +126,9 @@ int prg_buff_mod67_cached(mpcx_ctx *ctx, u64 seed, u64 lcg, u64 first, u64 count
 int prg_fill_buff_mod67_listed(mpcx_ctx *ctx, u64 seed, u64 lcg, u64 first, u64 n_elems, int zero_to_one, const u32 *list,
                                const u32 *listed, u8 *out);
 void prg_rand_cache_clear(mpcx_ctx *ctx);
+// the checkpoint tables of a device keep their superseded device copies while any context of the device is open
+void prg_tables_context_opened(int device);
+void prg_tables_context_closed(int device);
 // Z_67 sharing of the 64 bits of v[i]: first[i][k] = rnd[64 i + k] (one byte, already % 67),
 // second[i][k] = (bit_k(v[i]) + 67 - first[i][k]) % 67; first / second are 16-byte aligned
 int snn_bit_share_launch(mpcx_ctx *ctx, const u64 *v, const u8 *rnd, u64 n, u16 *first, u16 *second);

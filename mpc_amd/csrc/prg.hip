@@ -5,8 +5,14 @@
 // 24-byte state every PRG_CK outputs; one GPU lane then replays one PRG_CK-word segment.  A
 // 256-thread workgroup therefore owns 256 consecutive segments; every 16 steps the lanes
 // park their words in LDS and the workgroup writes them out as whole 128-byte lines.
+#include <unistd.h>
+
+#include <condition_variable>
+#include <deque>
 #include <map>
 #include <mutex>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "mpcx_internal.h"
@@ -14,9 +20,6 @@
 
 namespace {
 
-struct HostState {
-    u64 seed, lcg, hash;
-};
 struct Table {
     std::mutex mu; // walk and upload of THIS stream; streams are extended independently of one another
     std::vector<PrgCk> host; // host[e] = state before stream word PRG_CK*e
@@ -24,8 +27,11 @@ struct Table {
     u64 dev_cap = 0, dev_count = 0;
     // Older, smaller device copies.  A table is shared by every context of the device, so a kernel of another
     // thread may still read (or be about to be launched on) a copy when the table grows: copies are kept until the
-    // process ends.  Growth is geometric, so together they hold less than the live copy.
+    // last context of the device shuts down.  Growth is geometric, so together they hold less than the live copy.
     std::vector<PrgCk *> retired;
+    u64 bg_target = 0;    // checkpoints the background walker has been asked for
+    u64 last_need = 0;    // the previous request, for the rate at which the stream is consumed
+    u64 loaded_from_disk = 0, saved_to_disk = 0;
 };
 struct Key {
     int device;
@@ -36,11 +42,173 @@ struct Key {
         return lcg < o.lcg;
     }
 };
-std::mutex g_mu; // guards the map itself (its nodes never move)
-std::map<Key, Table> g_tables;
+// The registry and the walker's queue are never destroyed: the background thread may still run at process exit.
+struct Registry {
+    std::mutex mu; // guards the map itself (its nodes never move)
+    std::map<Key, Table> tables;
+    std::map<int, int> live_contexts; // per device
+    // background walker: one thread, jobs = (table, device)
+    std::mutex qmu;
+    std::condition_variable qcv;
+    std::deque<std::pair<Table *, Key>> queue;
+    bool walker_started = false, stop = false, walker_busy = false;
+};
+Registry &reg() {
+    static Registry *r = new Registry();
+    return *r;
+}
 Table &table_of(int device, u64 seed, u64 lcg) {
-    std::lock_guard<std::mutex> g(g_mu);
-    return g_tables[Key{device, seed, lcg}];
+    Registry &R = reg();
+    std::lock_guard<std::mutex> g(R.mu);
+    return R.tables[Key{device, seed, lcg}];
+}
+
+// ---- checkpoints kept on disk.  The keys of the engines are compile-time constants (mpc_engine/ABY3Engine.hpp:10-15),
+// so the serial walk of a stream is the same work in every process and on every rank: with MPCX_CKPT_CACHE=<dir>
+// a table is read from <dir>/prg_<seed>_<lcg>.ckpt before anything is walked, and written back (to a temporary
+// name, then renamed) when it has grown by more than a quarter.  File = 32-byte header {magic, seed, lcg, count}
+// followed by count checkpoints.
+const u64 CKPT_MAGIC = 0x3143504B435850ull + ((u64)PRG_CK << 56);
+std::string ckpt_path(u64 seed, u64 lcg) {
+    const char *dir = getenv("MPCX_CKPT_CACHE");
+    if (!dir || !*dir) return std::string();
+    char name[96];
+    snprintf(name, sizeof name, "/prg_%016llx_%016llx.ckpt", (unsigned long long)seed, (unsigned long long)lcg);
+    return std::string(dir) + name;
+}
+void ckpt_load(Table &T, u64 seed, u64 lcg) {
+    const std::string path = ckpt_path(seed, lcg);
+    if (path.empty()) return;
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) return;
+    u64 hdr[4];
+    if (fread(hdr, 8, 4, f) == 4 && hdr[0] == CKPT_MAGIC && hdr[1] == seed && hdr[2] == lcg && hdr[3] > T.host.size() &&
+        hdr[3] < (1ull << 36)) {
+        std::vector<PrgCk> v(hdr[3]);
+        // a file that another process is replacing is complete or absent (rename); a short read is ignored
+        if (fread(v.data(), sizeof(PrgCk), hdr[3], f) == hdr[3] && !T.host.empty() && v[0].seed == T.host[0].seed &&
+            v[0].lcg == T.host[0].lcg && v[0].hash == T.host[0].hash) {
+            T.host.swap(v);
+            T.loaded_from_disk = T.saved_to_disk = T.host.size();
+        }
+    }
+    fclose(f);
+}
+void ckpt_save(Table &T, u64 seed, u64 lcg) {
+    const std::string path = ckpt_path(seed, lcg);
+    if (path.empty() || T.host.size() <= T.saved_to_disk + T.saved_to_disk / 4 + 4096) return;
+    char tmp[32];
+    snprintf(tmp, sizeof tmp, ".tmp.%ld", (long)getpid());
+    const std::string tpath = path + tmp;
+    FILE *f = fopen(tpath.c_str(), "wb");
+    if (!f) return;
+    const u64 hdr[4] = {CKPT_MAGIC, seed, lcg, (u64)T.host.size()};
+    const bool ok = fwrite(hdr, 8, 4, f) == 4 && fwrite(T.host.data(), sizeof(PrgCk), T.host.size(), f) == T.host.size();
+    if (fclose(f) == 0 && ok && rename(tpath.c_str(), path.c_str()) == 0)
+        T.saved_to_disk = T.host.size();
+    else
+        remove(tpath.c_str());
+}
+
+// extends T.host to at least `want` checkpoints (T.mu held)
+void walk_to(Table &T, u64 want) {
+    if (T.host.size() >= want) return;
+    if (want > T.host.capacity()) { // grow the host copy geometrically (reserve alone would allocate exactly)
+        const u64 geo = T.host.capacity() + T.host.capacity() / 2;
+        T.host.reserve(want > geo ? want : geo);
+    }
+    PrgCk c = T.host.back();
+    while (T.host.size() < want) {
+        for (u64 i = 0; i < PRG_CK; i++) prv_step(c.seed, c.lcg, c.hash);
+        T.host.push_back(c);
+    }
+}
+// mirrors T.host on the device (T.mu held, the device current); returns a hipError_t
+hipError_t upload(Table &T) {
+    const u64 have = T.host.size();
+    if (T.dev_count >= have) return hipSuccess;
+    if (T.dev_cap < have) {
+        // the first copy is sized to the request; a table that grows again is a pop stream on the move and gets
+        // half as much spare room again, so that the superseded copies stay a geometric series
+        const u64 room = (T.dev && have / 2 > 4096) ? have / 2 : 4096;
+        const u64 cap = have + room;
+        PrgCk *nd = nullptr;
+        hipError_t e = hipMalloc((void **)&nd, cap * sizeof(PrgCk));
+        if (e != hipSuccess) return e;
+        if (T.dev) T.retired.push_back(T.dev);
+        T.dev = nd;
+        T.dev_cap = cap;
+        T.dev_count = 0;
+    }
+    hipError_t e = hipMemcpy(T.dev + T.dev_count, T.host.data() + T.dev_count, (have - T.dev_count) * sizeof(PrgCk),
+                             hipMemcpyHostToDevice);
+    if (e == hipSuccess) T.dev_count = have;
+    return e;
+}
+
+// The background walker: a pop stream is consumed a little further by every engine call, and its serial walk
+// (~1 ns per word on one core) would otherwise sit in front of every call.  After a request has been served, the
+// walker carries the table on to bg_target in slices, taking the table's lock only for a slice at a time.
+void walker_main() {
+    Registry &R = reg();
+    for (;;) {
+        std::pair<Table *, Key> job;
+        {
+            std::unique_lock<std::mutex> lk(R.qmu);
+            R.walker_busy = false;
+            R.qcv.notify_all();
+            R.qcv.wait(lk, [&] { return R.stop || !R.queue.empty(); });
+            if (R.stop) return;
+            job = R.queue.front();
+            R.queue.pop_front();
+            R.walker_busy = true;
+        }
+        Table &T = *job.first;
+        if (hipSetDevice(job.second.device) != hipSuccess) continue;
+        for (;;) {
+            {
+                std::lock_guard<std::mutex> lk(R.qmu);
+                if (R.stop) break;
+            }
+            std::lock_guard<std::mutex> g(T.mu);
+            if (T.host.size() >= T.bg_target) {
+                (void)upload(T);
+                ckpt_save(T, job.second.seed, job.second.lcg);
+                break;
+            }
+            const u64 slice = T.host.size() + 32768; // ~2 M words, a few milliseconds
+            walk_to(T, slice < T.bg_target ? slice : T.bg_target);
+        }
+    }
+}
+// at process exit (registered after the HIP runtime came up, so it runs before the runtime is torn down): the walker
+// finishes its slice and stops
+void walker_stop() {
+    Registry &R = reg();
+    std::unique_lock<std::mutex> lk(R.qmu);
+    R.stop = true;
+    R.qcv.notify_all();
+    R.qcv.wait(lk, [&] { return !R.walker_busy; });
+}
+void walk_ahead(Table &T, const Key &key, u64 target) { // T.mu held
+    static const bool on = [] {
+        const char *e = getenv("MPCX_PRG_WALK_AHEAD");
+        return !(e && atoi(e) == 0);
+    }();
+    if (!on || target <= T.bg_target || target <= T.host.size()) return;
+    const bool queued = T.bg_target > T.host.size(); // a job for this table is still running
+    T.bg_target = target;
+    if (queued) return;
+    Registry &R = reg();
+    std::lock_guard<std::mutex> lk(R.qmu);
+    if (R.stop) return;
+    if (!R.walker_started) {
+        R.walker_started = true;
+        atexit(walker_stop);
+        std::thread(walker_main).detach();
+    }
+    R.queue.emplace_back(&T, key);
+    R.qcv.notify_one();
 }
 
 // mode 0: every stream word -> out64[rel]                                  (pop stream)
@@ -157,45 +325,51 @@ int mpcx_prg_table(mpcx_ctx *ctx, u64 seed, u64 lcg, u64 t_end, const PrgCk **de
         u64 s = seed, l = lcg, h = 0;
         for (int i = 0; i < 5; i++) prv_step(s, l, h); // utils/PRgenerator.cpp:23-26
         T.host.push_back(PrgCk{s, l, h});
+        ckpt_load(T, seed, lcg);
     }
     const u64 need = t_end / PRG_CK + 1; // checkpoints 0 .. floor(t_end/PRG_CK)
     if (T.host.size() < need) {
-        // A pop stream is consumed a little further by every call: walk some way past the request (1/8 more,
-        // between 4 Ki and 64 Ki checkpoints) so that the table -- and its device copy -- grows once in many calls.
+        // walk a little past the request (between 4 Ki and 64 Ki checkpoints) so that the device copy grows once in
+        // many calls
         u64 ahead = need / 8;
         ahead = ahead < 4096 ? 4096 : ahead > 65536 ? 65536 : ahead;
-        const u64 want = need + ahead;
-        if (want > T.host.capacity()) { // grow the host copy geometrically too (reserve alone would allocate exactly)
-            const u64 geo = T.host.capacity() + T.host.capacity() / 2;
-            T.host.reserve(want > geo ? want : geo);
-        }
-        PrgCk c = T.host.back();
-        while (T.host.size() < want) {
-            for (u64 i = 0; i < PRG_CK; i++) prv_step(c.seed, c.lcg, c.hash);
-            T.host.push_back(c);
-        }
+        walk_to(T, need + ahead);
+        ckpt_save(T, seed, lcg);
+    }
+    // The background walker keeps the table ahead of a stream that is being consumed: four times the step from the
+    // previous request, within 16 Mi .. 256 Mi words, started when less than half of that is left.
+    {
+        const u64 step = need > T.last_need ? need - T.last_need : 0;
+        if (need > T.last_need) T.last_need = need;
+        u64 more = 4 * step;
+        const u64 lo = (16ull << 20) / PRG_CK, hi = (256ull << 20) / PRG_CK;
+        more = more < lo ? lo : more > hi ? hi : more;
+        if (T.host.size() < need + more / 2) walk_ahead(T, Key{ctx->device, seed, lcg}, need + more);
     }
     if (T.dev_count < need) {
         MPCX_HIP(hipSetDevice(ctx->device));
-        const u64 have = T.host.size();
-        if (T.dev_cap < have) {
-            // the first copy is sized to the request; a table that grows again is a pop stream on the move and gets
-            // half as much spare room again, so that the superseded copies stay a geometric series
-            const u64 room = (T.dev && have / 2 > 4096) ? have / 2 : 4096;
-            const u64 cap = have + room;
-            PrgCk *nd = nullptr;
-            MPCX_HIP(hipMalloc((void **)&nd, cap * sizeof(PrgCk)));
-            if (T.dev) T.retired.push_back(T.dev);
-            T.dev = nd;
-            T.dev_cap = cap;
-            T.dev_count = 0;
-        }
-        MPCX_HIP(hipMemcpy(T.dev + T.dev_count, T.host.data() + T.dev_count, (have - T.dev_count) * sizeof(PrgCk),
-                           hipMemcpyHostToDevice));
-        T.dev_count = have;
+        MPCX_HIP(upload(T));
     }
     *dev = T.dev;
     return 0;
+}
+
+// the last context of a device has shut down: no kernel can read the superseded device copies any more
+void prg_tables_context_opened(int device) {
+    Registry &R = reg();
+    std::lock_guard<std::mutex> g(R.mu);
+    R.live_contexts[device]++;
+}
+void prg_tables_context_closed(int device) {
+    Registry &R = reg();
+    std::lock_guard<std::mutex> g(R.mu);
+    if (--R.live_contexts[device] > 0) return;
+    for (auto &kv : R.tables)
+        if (kv.first.device == device) {
+            std::lock_guard<std::mutex> t(kv.second.mu);
+            for (PrgCk *p : kv.second.retired) (void)hipFree(p);
+            kv.second.retired.clear();
+        }
 }
 
 static int prg_launch(mpcx_ctx *ctx, u64 seed, u64 lcg, u64 t_first, u64 t_end, int mode, u64 *out64, u8 *out8) {

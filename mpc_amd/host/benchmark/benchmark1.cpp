@@ -7,7 +7,7 @@
 //   * without arguments the three parties run as three threads of this process over InProcMessenger (all on
 //     MPCX_DEVICE, default GPU 0); with a party id it is one party of a three-process run over SocketMessenger,
 //     as the reference driver is.
-// usage: benchmark1 [party_id] [--width W] [--vec N] [--repeat R] [--no-mlp]
+// usage: benchmark1 [party_id] [--width W] [--vec N] [--repeat R] [--engine aby3|securenn|my] [--no-mlp]
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -25,6 +25,7 @@
 struct Options {
     size_t width = 200, vec = 0, repeat = 10;
     bool mlp = true;
+    const char *engine = nullptr; // run only this engine's lines: "aby3", "securenn" or "my"
 };
 static std::atomic<int> failures{0};
 #define CHECK(cond)                                                                   \
@@ -310,10 +311,11 @@ static void bench_mlp(VirtuleMessenger *messenger, size_t party, const Options &
 }
 
 static void party_main(VirtuleMessenger *messenger, size_t party, const Options &opt) {
-    bench_aby3(messenger, party, opt);
-    bench_securenn(messenger, party, opt);
-    bench_me(messenger, party, opt);
-    if (opt.mlp) bench_mlp(messenger, party, opt);
+    const auto wanted = [&](const char *name) { return !opt.engine || !strcmp(opt.engine, name); };
+    if (wanted("aby3")) bench_aby3(messenger, party, opt);
+    if (wanted("securenn")) bench_securenn(messenger, party, opt);
+    if (wanted("my")) bench_me(messenger, party, opt);
+    if (opt.mlp && wanted("securenn")) bench_mlp(messenger, party, opt);
 }
 
 int main(int argc, char const *argv[]) {
@@ -326,12 +328,14 @@ int main(int argc, char const *argv[]) {
             opt.vec = strtoul(argv[++i], NULL, 10);
         else if (!strcmp(argv[i], "--repeat") && i + 1 < argc)
             opt.repeat = strtoul(argv[++i], NULL, 10);
+        else if (!strcmp(argv[i], "--engine") && i + 1 < argc)
+            opt.engine = argv[++i];
         else if (!strcmp(argv[i], "--no-mlp"))
             opt.mlp = false;
         else if (argv[i][0] >= '0' && argv[i][0] <= '2' && argv[i][1] == 0)
             party = argv[i][0] - '0';
         else {
-            printf("usage:\nbenchmark1 [party_id in {0,1,2}] [--width W] [--vec N] [--repeat R] [--no-mlp]\n");
+            printf("usage:\nbenchmark1 [party_id in {0,1,2}] [--width W] [--vec N] [--repeat R] [--engine aby3|securenn|my] [--no-mlp]\n");
             return 1;
         }
     }

@@ -1,15 +1,17 @@
 // In-process VirtuleMessenger: the three parties are three threads of one process sharing a Hub.
-// One round = post the outgoing payloads into the hub's mailboxes, barrier, collect, barrier.
+// One round = post the addresses of the outgoing payloads in the hub, barrier, every receiver copies its payloads out
+// of the senders' buffers (one copy per message, by the library's multi-threaded host copy), barrier.
 // (The reference ships no in-process messenger; its tests use three OS processes over TCP.)
 #pragma once
 #include <condition_variable>
 #include <mutex>
 
+#include "../../../include/mpcx.h"
 #include "VirtuleMessenger.hpp"
 
 class InProcHub {
   public:
-    string box[3][3]; // box[from][to]
+    const string *box[3][3] = {}; // box[from][to]: the sender's own buffer, valid until the round's second barrier
     size_t bytes_sent[3] = {0, 0, 0};
     size_t rounds[3] = {0, 0, 0};
     void arrive() {
@@ -38,14 +40,18 @@ class InProcMessenger : public VirtuleMessenger {
     void send_and_recv(const vector<string> &message_send, vector<string> &message_recv) override {
         for (size_t to = 0; to < 3; to++)
             if (to != party_id) {
-                hub->box[party_id][to] = message_send[to];
+                hub->box[party_id][to] = &message_send[to];
                 hub->bytes_sent[party_id] += message_send[to].size();
             }
         hub->rounds[party_id]++;
         hub->arrive();
         message_recv.resize(3);
         for (size_t from = 0; from < 3; from++)
-            if (from != party_id) message_recv[from] = hub->box[from][party_id];
+            if (from != party_id) {
+                const string &src = *hub->box[from][party_id];
+                message_recv[from].resize(src.size());
+                if (!src.empty()) mpcx_host_copy(&message_recv[from][0], src.data(), src.size());
+            }
         message_recv[party_id].clear();
         hub->arrive();
     }
