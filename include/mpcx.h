@@ -314,6 +314,31 @@ int mpcx_my_bit_inject_party_post(mpcx_ctx *ctx, int party, uint64_t seed2, uint
 /* reveal_vec_bools (:777-807): out = a ^ b, one byte per boolean */
 int mpcx_xor_bools(mpcx_ctx *ctx, const int8_t *a, const int8_t *b, int8_t *out, uint64_t n);
 
+/* ---- several GPUs behind one party (no counterpart in the reference, which is single-threaded host code) ----
+ * The path shards without any exchange between the devices: matrix_mul by row blocks of X (ABY3Engine.cpp:189-197:
+ * Y replicated, the mask words of a block start row0 * c words into both pop streams), the element-wise segments by
+ * contiguous element ranges (their (n_total, i0, n) arguments).  A group is one context per listed device (a device
+ * may be listed more than once) and one host thread per member; every member moves its own slice between host
+ * memory and its device, so the slices of a message land in the messenger-facing buffer directly. */
+typedef struct mpcx_group mpcx_group;
+int mpcx_group_init(const int *devices, int n, mpcx_group **out); /* error text: mpcx_last_error(NULL) */
+int mpcx_group_shutdown(mpcx_group *g);
+int mpcx_group_size(const mpcx_group *g);
+mpcx_ctx *mpcx_group_ctx(mpcx_group *g, int member);
+const char *mpcx_group_last_error(mpcx_group *g);
+/* part `part` of `parts` contiguous parts of n items, in multiples of `granule` (the first parts are the larger ones) */
+int mpcx_plan_split(uint64_t n, int parts, int part, uint64_t granule, uint64_t *first, uint64_t *count);
+/* fn(ctx, member, first, count, user) for every member's range of [0, n), each on its member's thread with the
+ * member's device current; returns the first non-zero result.  A vector shorter than one granule per member uses
+ * fewer members. */
+typedef int (*mpcx_member_fn)(mpcx_ctx *ctx, int member, uint64_t first, uint64_t count, void *user);
+int mpcx_group_for_each(mpcx_group *g, uint64_t n, uint64_t granule, mpcx_member_fn fn, void *user);
+/* mpcx_aby3_matmul_local over the group.  X0, X1, Y0, Y1 and Z0 are HOST pointers: every member uploads its rows of
+ * X and all of Y, multiplies, and writes its rows of Z0 (row-major) into place. */
+int mpcx_group_aby3_matmul_local(mpcx_group *g, const int64_t *X0, const int64_t *X1, const int64_t *Y0,
+                                 const int64_t *Y1, uint64_t r, uint64_t l, uint64_t c, int layout, uint64_t seed_next,
+                                 uint64_t pop_next, uint64_t seed_prev, uint64_t pop_prev, int64_t *Z0);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,231 @@
+// Several GPUs behind one party: a group is one context per device plus one host thread per member.  The path
+// shards without any exchange between the members -- matrix products by row blocks of X (Y replicated, the mask
+// words of a block start row0 * c words into both pop streams), element-wise segments by contiguous element ranges
+// (n_total, i0, n) -- and every member moves its own slice between host memory and its device, so the blocks of a
+// message land in the messenger-facing host buffer directly, with no gather between the devices.
+#include <cstdarg>
+#include <condition_variable>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <thread>
+
+#include "mpcx_internal.h"
+
+struct mpcx_group {
+    std::vector<mpcx_ctx *> ctx;
+    std::string err;
+    // one worker per member, bound to the member's device; a call hands every worker one job and waits for all
+    struct Worker {
+        std::thread th;
+        std::mutex mu;
+        std::condition_variable cv;
+        std::function<int()> job;
+        bool has_job = false, done = false, quit = false;
+        int rc = 0;
+    };
+    std::vector<std::unique_ptr<Worker>> workers;
+};
+
+namespace {
+
+void worker_main(mpcx_group::Worker *w, int device) {
+    (void)hipSetDevice(device);
+    for (;;) {
+        std::unique_lock<std::mutex> lk(w->mu);
+        w->cv.wait(lk, [&] { return w->has_job || w->quit; });
+        if (w->quit) return;
+        std::function<int()> job = std::move(w->job);
+        w->has_job = false;
+        lk.unlock();
+        const int rc = job();
+        lk.lock();
+        w->rc = rc;
+        w->done = true;
+        w->cv.notify_all();
+    }
+}
+
+int group_fail(mpcx_group *g, const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (g)
+        g->err = buf;
+    else
+        mpcx_fail(nullptr, "%s", buf);
+    return 1;
+}
+
+// runs job(member) on every member's thread (member 0 on the caller's own thread) and collects the first error
+template <class F> int group_run(mpcx_group *g, int members, F job) {
+    for (int k = 1; k < members; k++) {
+        mpcx_group::Worker &w = *g->workers[k];
+        std::lock_guard<std::mutex> lk(w.mu);
+        w.job = [=] { return job(k); };
+        w.has_job = true;
+        w.done = false;
+        w.cv.notify_all();
+    }
+    int rc = 0;
+    if (members > 0) {
+        (void)hipSetDevice(g->ctx[0]->device);
+        rc = job(0);
+        if (rc) g->err = "member 0: " + g->ctx[0]->err;
+    }
+    for (int k = 1; k < members; k++) {
+        mpcx_group::Worker &w = *g->workers[k];
+        std::unique_lock<std::mutex> lk(w.mu);
+        w.cv.wait(lk, [&] { return w.done; });
+        if (w.rc && !rc) {
+            rc = w.rc;
+            g->err = "member " + std::to_string(k) + ": " + g->ctx[k]->err;
+        }
+    }
+    return rc;
+}
+
+} // namespace
+
+extern "C" {
+
+int mpcx_plan_split(uint64_t n, int parts, int part, uint64_t granule, uint64_t *first, uint64_t *count) {
+    if (!first || !count || parts < 1 || part < 0 || part >= parts) return 1;
+    if (granule == 0) granule = 1;
+    const u64 units = ceil_div(n, granule);
+    const u64 base = units / (u64)parts, rem = units % (u64)parts; // the first `rem` parts take one unit more
+    const u64 u0 = (u64)part * base + ((u64)part < rem ? (u64)part : rem);
+    const u64 un = base + ((u64)part < rem ? 1 : 0);
+    u64 f = u0 * granule, e = (u0 + un) * granule;
+    if (f > n) f = n;
+    if (e > n) e = n;
+    *first = f;
+    *count = e - f;
+    return 0;
+}
+
+int mpcx_group_init(const int *devices, int n, mpcx_group **out) {
+    if (!out || !devices || n < 1 || n > 64) return group_fail(nullptr, "mpcx_group_init: bad arguments (n = %d)", n);
+    mpcx_group *g = new mpcx_group();
+    for (int k = 0; k < n; k++) {
+        mpcx_ctx *c = nullptr;
+        if (mpcx_init(devices[k], &c)) { // the text is in the init error slot
+            for (mpcx_ctx *p : g->ctx) mpcx_shutdown(p);
+            delete g;
+            return 1;
+        }
+        g->ctx.push_back(c);
+    }
+    g->workers.resize(n);
+    for (int k = 1; k < n; k++) {
+        g->workers[k].reset(new mpcx_group::Worker());
+        g->workers[k]->th = std::thread(worker_main, g->workers[k].get(), devices[k]);
+    }
+    *out = g;
+    return 0;
+}
+
+int mpcx_group_shutdown(mpcx_group *g) {
+    if (!g) return 0;
+    for (size_t k = 1; k < g->workers.size(); k++) {
+        mpcx_group::Worker &w = *g->workers[k];
+        {
+            std::lock_guard<std::mutex> lk(w.mu);
+            w.quit = true;
+            w.cv.notify_all();
+        }
+        w.th.join();
+    }
+    for (mpcx_ctx *c : g->ctx) mpcx_shutdown(c);
+    delete g;
+    return 0;
+}
+
+int mpcx_group_size(const mpcx_group *g) { return g ? (int)g->ctx.size() : 0; }
+mpcx_ctx *mpcx_group_ctx(mpcx_group *g, int member) {
+    return (g && member >= 0 && member < (int)g->ctx.size()) ? g->ctx[member] : nullptr;
+}
+const char *mpcx_group_last_error(mpcx_group *g) { return g ? g->err.c_str() : mpcx_last_error(nullptr); }
+
+int mpcx_group_for_each(mpcx_group *g, uint64_t n, uint64_t granule, mpcx_member_fn fn, void *user) {
+    if (!g || !fn) return group_fail(g, "mpcx_group_for_each: NULL argument");
+    const int size = (int)g->ctx.size();
+    // a vector too short to give every member a granule runs on the first members only
+    int members = size;
+    const u64 units = ceil_div(n, granule ? granule : 1);
+    if (units < (u64)members) members = units ? (int)units : 1;
+    return group_run(g, members, [=](int k) {
+        u64 first = 0, count = 0;
+        mpcx_plan_split(n, members, k, granule, &first, &count);
+        return fn(g->ctx[k], k, first, count, user);
+    });
+}
+
+int mpcx_group_aby3_matmul_local(mpcx_group *g, const int64_t *X0, const int64_t *X1, const int64_t *Y0,
+                                 const int64_t *Y1, uint64_t r, uint64_t l, uint64_t c, int layout, uint64_t seed_next,
+                                 uint64_t pop_next, uint64_t seed_prev, uint64_t pop_prev, int64_t *Z0) {
+    if (!g) return group_fail(g, "mpcx_group_aby3_matmul_local: the group is NULL");
+    if (!(X0 && X1 && Y0 && Y1 && Z0)) return group_fail(g, "mpcx_group_aby3_matmul_local: NULL operand");
+    if (!(r && l && c)) return group_fail(g, "mpcx_group_aby3_matmul_local: empty shape");
+    if (layout != 0 && layout != 1) return group_fail(g, "mpcx_group_aby3_matmul_local: layout must be 0 or 1");
+    int members = (int)g->ctx.size();
+    const u64 granule = 128; // rows of a block tile of the digit-pair kernel
+    if (ceil_div(r, granule) < (u64)members) members = (int)ceil_div(r, granule);
+    return group_run(g, members, [=](int k) -> int {
+        mpcx_ctx *ctx = g->ctx[k];
+        u64 row0 = 0, rows = 0;
+        mpcx_plan_split(r, members, k, granule, &row0, &rows);
+        if (rows == 0) return 0;
+        // device copies: the member's rows of X0 / X1 (row-major), all of Y0 / Y1 (row-major), its rows of Z0
+        void *px0 = nullptr, *px1 = nullptr, *py0 = nullptr, *py1 = nullptr, *pz = nullptr, *tmp = nullptr;
+        auto release = [&](int rc) {
+            for (void *p : {px0, px1, py0, py1, pz, tmp}) (void)mpcx_free(ctx, p);
+            return rc;
+        };
+#define G_TRY(call)                                                                                                    \
+    do {                                                                                                               \
+        if ((call) != 0) return release(1);                                                                            \
+    } while (0)
+        G_TRY(mpcx_malloc(ctx, 8 * rows * l, &px0));
+        G_TRY(mpcx_malloc(ctx, 8 * rows * l, &px1));
+        G_TRY(mpcx_malloc(ctx, 8 * l * c, &py0));
+        G_TRY(mpcx_malloc(ctx, 8 * l * c, &py1));
+        G_TRY(mpcx_malloc(ctx, 8 * rows * c, &pz));
+        if (layout == 0) {
+            G_TRY(mpcx_h2d(ctx, px0, X0 + row0 * l, 8 * rows * l));
+            G_TRY(mpcx_h2d(ctx, px1, X1 + row0 * l, 8 * rows * l));
+            G_TRY(mpcx_h2d(ctx, py0, Y0, 8 * l * c));
+            G_TRY(mpcx_h2d(ctx, py1, Y1, 8 * l * c));
+        } else {
+            // column-major operands (how Eigen stores MatrixXl): rows of X are strided on the host, so the whole
+            // matrix goes up and is turned on the device; the member keeps its rows
+            const u64 big = r * l > l * c ? r * l : l * c;
+            G_TRY(mpcx_malloc(ctx, 8 * big, &tmp));
+            void *full = nullptr;
+            G_TRY(mpcx_malloc(ctx, 8 * r * l, &full));
+            for (int s = 0; s < 2; s++) {
+                int rc = mpcx_h2d(ctx, tmp, s ? X1 : X0, 8 * r * l);
+                if (!rc) rc = mpcx_relayout(ctx, (const i64 *)tmp, (i64 *)full, r, l, 1, 0);
+                if (!rc) rc = mpcx_d2d(ctx, s ? px1 : px0, (const i64 *)full + row0 * l, 8 * rows * l);
+                if (rc) {
+                    (void)mpcx_free(ctx, full);
+                    return release(1);
+                }
+            }
+            (void)mpcx_free(ctx, full);
+            G_TRY(mpcx_h2d(ctx, tmp, Y0, 8 * l * c));
+            G_TRY(mpcx_relayout(ctx, (const i64 *)tmp, (i64 *)py0, l, c, 1, 0));
+            G_TRY(mpcx_h2d(ctx, tmp, Y1, 8 * l * c));
+            G_TRY(mpcx_relayout(ctx, (const i64 *)tmp, (i64 *)py1, l, c, 1, 0));
+        }
+        G_TRY(mpcx_aby3_matmul_local_rows(ctx, (const i64 *)px0, (const i64 *)px1, (const i64 *)py0, (const i64 *)py1, rows,
+                                          l, c, row0, seed_next, pop_next, seed_prev, pop_prev, (i64 *)pz));
+        G_TRY(mpcx_d2h(ctx, Z0 + row0 * c, pz, 8 * rows * c)); // straight into the caller's (messenger-facing) buffer
+#undef G_TRY
+        return release(0);
+    });
+}
+
+} // extern "C"

@@ -1,5 +1,7 @@
 #include "ABY3Engine.hpp"
 
+#include <memory>
+
 #include "gpu_support.hpp"
 
 using mpcgpu::Dev;
@@ -19,10 +21,172 @@ ABY3Engine::ABY3Engine(VirtuleMessenger *_messenger, size_t _party_id) : messeng
     static const uint64_t pair_key[3][3] = {{KEY0, KEY01, KEY20}, {KEY01, KEY1, KEY12}, {KEY20, KEY12, KEY2}};
     assert(party_id < 3);
     for (size_t k = 0; k < 3; k++) prgs.push_back(PRgenerator(pair_key[party_id][k], 0));
-    gpu = mpcgpu::open_context();
+    group = mpcgpu::open_group();
+    gpu = group ? mpcx_group_ctx(group, 0) : mpcgpu::open_context();
 }
 
-ABY3Engine::~ABY3Engine() { mpcx_shutdown(gpu); }
+ABY3Engine::~ABY3Engine() {
+    if (group)
+        mpcx_group_shutdown(group);
+    else
+        mpcx_shutdown(gpu);
+}
+
+// ---- the same protocols over a group of GPUs.  Every member works on a contiguous range of the elements (whole
+// multiples of 64, so that the dense bit strings of msb split at word boundaries) with its own device buffers, and
+// moves its slices of the operands, of the messages and of the results itself; the rounds and the wire bytes are
+// those of the single-GPU methods.
+namespace {
+template <class T> using DevVec = std::vector<std::unique_ptr<Dev<T>>>;
+constexpr uint64_t RANGE_GRANULE = 64;
+constexpr size_t W8 = sizeof(int64_t);
+
+void add_prepare_group(ABY3Engine &e, const array<VecI64, 2> &Xj, array<VecI64, 2> &Gj, array<VecI64, 2> &Pj) {
+    const Peers pe(e.party_id);
+    const size_t n = Xj[0].size(), G = mpcx_group_size(e.group);
+    DevVec<int64_t> x0(G), x1(G), c0(G), c1(G), p0(G), p1(G), g0(G);
+    string &out = e.message_send[pe.prev];
+    e.message_send[pe.next].clear();
+    out.resize(n * W8);
+    mpcgpu::group_for_each(e.group, n, RANGE_GRANULE, [&](mpcx_ctx *ctx, int m, uint64_t i0, uint64_t cnt) {
+        x0[m].reset(new Dev<int64_t>(ctx, Xj[0].data() + i0, cnt));
+        x1[m].reset(new Dev<int64_t>(ctx, Xj[1].data() + i0, cnt));
+        c0[m].reset(new Dev<int64_t>(ctx, cnt));
+        GPU_OK(ctx, mpcx_aby3_add_prepare_step1(ctx, *x0[m], *x1[m], cnt, *c0[m]));
+        if (cnt) c0[m]->down(&out[i0 * W8], cnt);
+    });
+    e.messenger->send_and_recv(e.message_send, e.message_recv);
+    const string &in = e.message_recv[pe.next];
+    MSG_CHECK(in.size() == n * W8);
+    Pj[0].resize(n);
+    Pj[1].resize(n);
+    mpcgpu::group_for_each(e.group, n, RANGE_GRANULE, [&](mpcx_ctx *ctx, int m, uint64_t i0, uint64_t cnt) {
+        c1[m].reset(new Dev<int64_t>(ctx, (const int64_t *)in.data() + i0, cnt));
+        p0[m].reset(new Dev<int64_t>(ctx, cnt));
+        p1[m].reset(new Dev<int64_t>(ctx, cnt));
+        g0[m].reset(new Dev<int64_t>(ctx, cnt));
+        GPU_OK(ctx, mpcx_aby3_add_prepare_step2(ctx, *x0[m], *x1[m], *c0[m], *c1[m], cnt, *p0[m], *p1[m], *g0[m]));
+        if (cnt) {
+            g0[m]->down(&out[i0 * W8], cnt);
+            p0[m]->down(Pj[0].data() + i0, cnt);
+            p1[m]->down(Pj[1].data() + i0, cnt);
+        }
+    });
+    e.messenger->send_and_recv(e.message_send, e.message_recv);
+    string2vecI64(e.message_send[pe.prev], Gj[0]);
+    string2vecI64(e.message_recv[pe.next], Gj[1]);
+}
+
+void msb_group(ABY3Engine &e, const array<VecI64, 2> &Gj, const array<VecI64, 2> &Pj, array<vecbool, 2> &Zj) {
+    const Peers pe(e.party_id);
+    const size_t n = Gj[0].size(), G = mpcx_group_size(e.group);
+    DevVec<int64_t> g0(G), g1(G), p0(G), p1(G);
+    DevVec<uint64_t> state(G);
+    DevVec<int8_t> msg_in(G), msg_out(G), z0(G), z1(G);
+    string &out = e.message_send[pe.prev];
+    e.message_send[pe.next].clear();
+    out.resize(64 * n);
+    mpcgpu::group_for_each(e.group, n, RANGE_GRANULE, [&](mpcx_ctx *ctx, int m, uint64_t i0, uint64_t cnt) {
+        g0[m].reset(new Dev<int64_t>(ctx, Gj[0].data() + i0, cnt));
+        g1[m].reset(new Dev<int64_t>(ctx, Gj[1].data() + i0, cnt));
+        p0[m].reset(new Dev<int64_t>(ctx, Pj[0].data() + i0, cnt));
+        p1[m].reset(new Dev<int64_t>(ctx, Pj[1].data() + i0, cnt));
+        state[m].reset(new Dev<uint64_t>(ctx, 6 * cnt));
+        msg_in[m].reset(new Dev<int8_t>(ctx, 64 * cnt));
+        msg_out[m].reset(new Dev<int8_t>(ctx, 64 * cnt));
+        z0[m].reset(new Dev<int8_t>(ctx, cnt));
+        z1[m].reset(new Dev<int8_t>(ctx, cnt));
+        GPU_OK(ctx, mpcx_aby3_msb_begin(ctx, *g0[m], *g1[m], *p0[m], *p1[m], cnt, *state[m]));
+        GPU_OK(ctx, mpcx_aby3_msb_round_pre(ctx, *state[m], cnt, 32, *msg_out[m]));
+        if (cnt) msg_out[m]->down(&out[64 * i0], 64 * cnt);
+    });
+    Zj[0].resize(n);
+    Zj[1].resize(n);
+    for (size_t temp = 32; temp != 0; temp /= 2) {
+        const size_t per = 2 * temp; // message bytes per element of this round
+        out.resize(per * n);
+        e.messenger->send_and_recv(e.message_send, e.message_recv);
+        const string &in = e.message_recv[pe.next];
+        MSG_CHECK(in.size() == per * n);
+        if (temp != 1) out.resize(per / 2 * n); // the next message is written in place, slice by slice
+        mpcgpu::group_for_each(e.group, n, RANGE_GRANULE, [&](mpcx_ctx *ctx, int m, uint64_t i0, uint64_t cnt) {
+            if (!cnt) return;
+            GPU_OK(ctx, mpcx_h2d(ctx, msg_in[m]->p, in.data() + per * i0, per * cnt));
+            if (temp != 1) {
+                GPU_OK(ctx, mpcx_aby3_msb_round_mid(ctx, *state[m], cnt, temp, *msg_in[m], *msg_out[m]));
+                msg_out[m]->down(&out[per / 2 * i0], per / 2 * cnt);
+            } else {
+                GPU_OK(ctx, mpcx_aby3_msb_last(ctx, *state[m], cnt, *msg_in[m], *z0[m], *z1[m]));
+                z0[m]->down(Zj[0].data() + i0, cnt);
+                z1[m]->down(Zj[1].data() + i0, cnt);
+            }
+        });
+    }
+}
+
+// the sections of a bit_inject message hold n words each; a member's call produces / consumes `cnt` words per section
+void sections_down(const Dev<int64_t> &d, string &s, size_t sections, size_t n, size_t i0, size_t cnt) {
+    for (size_t k = 0; k < sections && cnt; k++) d.down(&s[(k * n + i0) * W8], cnt, k * cnt);
+}
+void sections_up(mpcx_ctx *ctx, Dev<int64_t> &d, const string &s, size_t sections, size_t n, size_t i0, size_t cnt) {
+    for (size_t k = 0; k < sections && cnt; k++) GPU_OK(ctx, mpcx_h2d(ctx, d.p + k * cnt, s.data() + (k * n + i0) * W8, cnt * W8));
+}
+
+void bit_inject_group(ABY3Engine &e, const array<VecI64, 2> &Aj, const array<vecbool, 2> &Bj, array<VecI64, 2> &Cj) {
+    const size_t n = Aj[0].size(), G = mpcx_group_size(e.group), id = e.party_id;
+    // party p talks to a = (p + 1) % 3 and b = (p + 2) % 3; message sizes in sections of n words (:590-620, :709-790, :875-939)
+    const size_t a = (id + 1) % 3, b = (id + 2) % 3;
+    static const size_t send_sections[3][3] = {{0, 2, 3}, {2, 0, 3}, {1, 1, 0}}; // [from][to]
+    // the two streams of this party, in the order the C ABI takes them
+    PRgenerator &sA = e.prgs[id == 0 ? 1 : 0], &sB = e.prgs[id == 2 ? 1 : 2]; // P0: s01, s20; P1: s01, s12; P2: s20, s12
+    const uint64_t popA = sA.pops, popB = sB.pops;
+    DevVec<int64_t> a0(G), a1(G), toA(G), toB(G), fromA(G), fromB(G), c0(G), c1(G);
+    DevVec<int8_t> b0(G), b1(G);
+    for (auto &m : e.message_send) m.clear();
+    e.message_send[a].resize(send_sections[id][a] * n * W8);
+    e.message_send[b].resize(send_sections[id][b] * n * W8);
+    mpcgpu::group_for_each(e.group, n, RANGE_GRANULE, [&](mpcx_ctx *ctx, int m, uint64_t i0, uint64_t cnt) {
+        a0[m].reset(new Dev<int64_t>(ctx, Aj[0].data() + i0, cnt));
+        a1[m].reset(new Dev<int64_t>(ctx, Aj[1].data() + i0, cnt));
+        b0[m].reset(new Dev<int8_t>(ctx, Bj[0].data() + i0, cnt));
+        b1[m].reset(new Dev<int8_t>(ctx, Bj[1].data() + i0, cnt));
+        toA[m].reset(new Dev<int64_t>(ctx, send_sections[id][a] * cnt));
+        toB[m].reset(new Dev<int64_t>(ctx, send_sections[id][b] * cnt));
+        if (id == 0) // to party 1, to party 2
+            GPU_OK(ctx, mpcx_aby3_bit_inject_p0_pre(ctx, *a0[m], *b0[m], *b1[m], n, i0, cnt, sA.init_seed, popA, sB.init_seed, popB, *toA[m], *toB[m]));
+        else if (id == 1) // to party 0 (= b), to party 2 (= a)
+            GPU_OK(ctx, mpcx_aby3_bit_inject_p1_pre(ctx, *a0[m], *a1[m], *b0[m], *b1[m], n, i0, cnt, sA.init_seed, popA, sB.init_seed, popB, *toB[m], *toA[m]));
+        else // to party 0 (= a), to party 1 (= b)
+            GPU_OK(ctx, mpcx_aby3_bit_inject_p2_pre(ctx, *b0[m], *b1[m], n, i0, cnt, sA.init_seed, popA, sB.init_seed, popB, *toA[m], *toB[m]));
+        sections_down(*toA[m], e.message_send[a], send_sections[id][a], n, i0, cnt);
+        sections_down(*toB[m], e.message_send[b], send_sections[id][b], n, i0, cnt);
+    });
+    sA.advance(e.gpu, (id == 2 ? 3 : 6) * n);
+    sB.advance(e.gpu, 3 * n);
+    e.messenger->send_and_recv(e.message_send, e.message_recv);
+    MSG_CHECK(e.message_recv[a].size() == send_sections[a][id] * n * W8 && e.message_recv[b].size() == send_sections[b][id] * n * W8);
+    Cj[0].resize(n);
+    Cj[1].resize(n);
+    mpcgpu::group_for_each(e.group, n, RANGE_GRANULE, [&](mpcx_ctx *ctx, int m, uint64_t i0, uint64_t cnt) {
+        fromA[m].reset(new Dev<int64_t>(ctx, send_sections[a][id] * cnt));
+        fromB[m].reset(new Dev<int64_t>(ctx, send_sections[b][id] * cnt));
+        c0[m].reset(new Dev<int64_t>(ctx, cnt));
+        c1[m].reset(new Dev<int64_t>(ctx, cnt));
+        sections_up(ctx, *fromA[m], e.message_recv[a], send_sections[a][id], n, i0, cnt);
+        sections_up(ctx, *fromB[m], e.message_recv[b], send_sections[b][id], n, i0, cnt);
+        if (id == 0) // from party 1, from party 2
+            GPU_OK(ctx, mpcx_aby3_bit_inject_p0_post(ctx, *b0[m], n, i0, cnt, sA.init_seed, popA, sB.init_seed, popB, *fromA[m], *fromB[m], *c0[m], *c1[m]));
+        else if (id == 1) // from party 0 (= b), from party 2 (= a)
+            GPU_OK(ctx, mpcx_aby3_bit_inject_p1_post(ctx, *b1[m], n, i0, cnt, sA.init_seed, popA, sB.init_seed, popB, *fromB[m], *fromA[m], *c0[m], *c1[m]));
+        else // from party 0 (= a), from party 1 (= b)
+            GPU_OK(ctx, mpcx_aby3_bit_inject_p2_post(ctx, *b0[m], *b1[m], n, i0, cnt, sA.init_seed, popA, sB.init_seed, popB, *fromA[m], *fromB[m], *c0[m], *c1[m]));
+        if (cnt) {
+            c0[m]->down(Cj[0].data() + i0, cnt);
+            c1[m]->down(Cj[1].data() + i0, cnt);
+        }
+    });
+}
+} // namespace
 
 // ---- sharing: R = pop(next) - pop(prev) (+ X on party 0); send share 0 to prev, share 1 comes from next
 void ABY3Engine::share(const VecI64 &X_plain, array<VecI64, 2> &Xj) {
@@ -152,18 +316,27 @@ void ABY3Engine::matrix_mul(const array<MatrixXl, 2> &Xj, const array<MatrixXl, 
     assert(Yj[0].rows() == lens);
     assert(Xj[1].rows() == rows && Xj[1].cols() == lens);
     assert(Yj[1].rows() == lens && Yj[1].cols() == cols);
-    Dev<int64_t> z(gpu, rows * cols);
-    {
+    message_send[pe.next].clear();
+    if (group && rows && lens && cols) {
+        // row blocks over the group's GPUs, each written into its place of the outgoing message
+        message_send[pe.prev].resize(rows * cols * sizeof(int64_t));
+        if (mpcx_group_aby3_matmul_local(group, Xj[0].data(), Xj[1].data(), Yj[0].data(), Yj[1].data(), rows, lens, cols, 1,
+                                         prgs[pe.next].init_seed, prgs[pe.next].pops, prgs[pe.prev].init_seed,
+                                         prgs[pe.prev].pops, (int64_t *)&message_send[pe.prev][0]) != 0) {
+            fprintf(stderr, "mpcx_group_aby3_matmul_local: %s\n", mpcx_group_last_error(group));
+            abort();
+        }
+    } else {
+        Dev<int64_t> z(gpu, rows * cols);
         Dev<int64_t> x0(gpu, Xj[0].data(), rows * lens), x1(gpu, Xj[1].data(), rows * lens);
         Dev<int64_t> y0(gpu, Yj[0].data(), lens * cols), y1(gpu, Yj[1].data(), lens * cols);
         // Eigen stores column-major (layout 1); the result comes back row-major = the wire order
         GPU_OK(gpu, mpcx_aby3_matmul_local(gpu, x0, x1, y0, y1, rows, lens, cols, 1, prgs[pe.next].init_seed,
                                            prgs[pe.next].pops, prgs[pe.prev].init_seed, prgs[pe.prev].pops, z));
+        z.to_string(message_send[pe.prev]);
     }
     prgs[pe.next].advance(gpu, rows * cols);
     prgs[pe.prev].advance(gpu, rows * cols);
-    message_send[pe.next].clear();
-    z.to_string(message_send[pe.prev]);
     messenger->send_and_recv(message_send, message_recv);
     Zj[0].resize(rows, cols);
     Zj[1].resize(rows, cols);
@@ -232,6 +405,7 @@ void ABY3Engine::add_prepare(const array<VecI64, 2> &Xj, array<VecI64, 2> &Gj, a
     const Peers pe(party_id);
     const size_t n = Xj[0].size();
     assert((size_t)Xj[1].size() == n);
+    if (group) return add_prepare_group(*this, Xj, Gj, Pj);
     Dev<int64_t> x0(gpu, Xj[0].data(), n), x1(gpu, Xj[1].data(), n), c0(gpu, n), c1(gpu, n);
     GPU_OK(gpu, mpcx_aby3_add_prepare_step1(gpu, x0, x1, n, c0));
     message_send[pe.next].clear();
@@ -266,6 +440,7 @@ void ABY3Engine::msb(const array<VecI64, 2> &Gj, const array<VecI64, 2> &Pj, arr
     const Peers pe(party_id);
     const size_t n = Gj[0].size();
     assert(n == (size_t)Gj[1].size() && n == (size_t)Pj[0].size() && n == (size_t)Pj[1].size());
+    if (group) return msb_group(*this, Gj, Pj, Zj);
     Dev<int64_t> p0(gpu, Pj[0].data(), n), p1(gpu, Pj[1].data(), n);
     Dev<uint64_t> state(gpu, 6 * n);
     Dev<int64_t> g0(gpu, Gj[0].data(), n), g1(gpu, Gj[1].data(), n); // read in place by the first round
@@ -323,6 +498,7 @@ void ABY3Engine::trunc(const array<VecI64, 2> &Xj, array<VecI64, 2> &Yj, size_t 
 void ABY3Engine::bit_inject(const array<VecI64, 2> &Aj, const array<vecbool, 2> &Bj, array<VecI64, 2> &Cj) {
     const size_t n = Aj[0].size();
     assert(n == (size_t)Aj[1].size() && n == Bj[0].size() && n == Bj[1].size());
+    if (group) return bit_inject_group(*this, Aj, Bj, Cj);
     const size_t w = n * sizeof(int64_t);
     for (auto &m : message_send) m.clear();
     Dev<int64_t> a0(gpu, Aj[0].data(), n), a1(gpu, Aj[1].data(), n), c0(gpu, n), c1(gpu, n);

@@ -30,6 +30,7 @@ using std::string;
 using std::vector;
 
 struct mpcx_ctx;
+struct mpcx_group;
 
 class ABY3Engine {
   public:
@@ -49,6 +50,9 @@ class ABY3Engine {
     vector<string> message_send; // three slots each, reused from call to call
     vector<string> message_recv;
     mpcx_ctx *gpu;               // this engine's GPU context (an addition)
+    // With MPCX_DEVICES=a,b,.. in the environment the engine spreads matrix_mul (row blocks) and add_prepare / msb /
+    // bit_inject (element ranges) over those GPUs; gpu is then the first member's context.  NULL otherwise.
+    mpcx_group *group;
 
     // ---- input: party 0 contributes the plain values, everyone ends up with its two shares (:63-127)
     void share(const VecI64 &plain, VecPair &out);

@@ -52,6 +52,40 @@ inline mpcx_ctx *open_context() {
     return ctx;
 }
 
+// MPCX_DEVICES=a,b,..: the GPUs one engine spreads its work over (NULL when fewer than two are listed)
+inline mpcx_group *open_group() {
+    const char *list = getenv("MPCX_DEVICES");
+    if (!list) return nullptr;
+    std::vector<int> devs;
+    for (const char *p = list; *p;) {
+        char *end;
+        const long v = strtol(p, &end, 10);
+        if (end == p) break;
+        devs.push_back((int)v);
+        p = *end == ',' ? end + 1 : end;
+    }
+    if (devs.size() < 2) return nullptr;
+    mpcx_group *g = nullptr;
+    if (mpcx_group_init(devs.data(), (int)devs.size(), &g) != 0) {
+        fprintf(stderr, "mpcx_group_init: %s\n", mpcx_last_error(nullptr));
+        abort();
+    }
+    return g;
+}
+// f(ctx, member, first, count) for every member's range of [0, n), on the members' threads
+template <class F> inline void group_for_each(mpcx_group *g, uint64_t n, uint64_t granule, F f) {
+    struct Thunk {
+        static int call(mpcx_ctx *ctx, int member, uint64_t first, uint64_t count, void *user) {
+            (*(F *)user)(ctx, member, first, count);
+            return 0;
+        }
+    };
+    if (mpcx_group_for_each(g, n, granule, &Thunk::call, &f) != 0) {
+        fprintf(stderr, "mpcx_group_for_each: %s\n", mpcx_group_last_error(g));
+        abort();
+    }
+}
+
 // typed device buffer owned by this object
 template <class T> class Dev {
   public:

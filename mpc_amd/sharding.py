@@ -12,11 +12,19 @@ Nothing here touches a GPU.  Two kinds of work shard naturally (no exchange insi
 """
 
 
-def split_range(total, parts, part):
-    """Contiguous, balanced split of range(total) into `parts`; returns (first, count) of `part`."""
-    base, rem = divmod(total, parts)
-    first = part * base + min(part, rem)
-    return first, base + (1 if part < rem else 0)
+def split_range(total, parts, part, granule=1):
+    """Contiguous, balanced split of range(total) into `parts`, in multiples of `granule`; returns (first, count) of
+    `part`.  The arithmetic is the library's own planner (mpcx_plan_split), the one the C++ engines and the group
+    entry points use, so that every layer cuts a vector in the same places."""
+    import ctypes
+
+    from .lib import load_library
+    first, count = ctypes.c_uint64(), ctypes.c_uint64()
+    rc = load_library().mpcx_plan_split(ctypes.c_uint64(total), ctypes.c_int(parts), ctypes.c_int(part),
+                                        ctypes.c_uint64(granule), ctypes.byref(first), ctypes.byref(count))
+    if rc:
+        raise ValueError(f"split_range({total}, {parts}, {part}, {granule}): bad arguments")
+    return first.value, count.value
 
 
 def matmul_row_block(r_total, world, rank):

@@ -1,0 +1,104 @@
+"""Several GPUs behind one party (mpcx_group_*): two contexts on the one GPU of the test box, driven through the
+group entry points, reproduce the single-context results bit for bit."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle_lib import KEY01, KEY20
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "mpc_amd", "host")
+U64, I32 = ctypes.c_uint64, ctypes.c_int
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import mpc_amd
+    L = mpc_amd.load_library()
+    L.mpcx_group_last_error.restype = ctypes.c_char_p
+    L.mpcx_group_ctx.restype = ctypes.c_void_p
+    return L
+
+
+def ptr(a):
+    return ctypes.c_void_p(a.ctypes.data)
+
+
+@pytest.mark.parametrize("members", [1, 2, 3])
+@pytest.mark.parametrize("r,l,c,layout", [(300, 70, 130, 0), (300, 70, 130, 1), (5, 4, 3, 1), (1000, 260, 520, 0)])
+def test_group_matmul_equals_the_oracle(lib, orc, members, r, l, c, layout):
+    """mpcx_group_aby3_matmul_local on host operands: the row blocks of the members, each written into its place
+    of Z0, are the whole product + mask of the CPU oracle (both operand layouts)."""
+    g = ctypes.c_void_p()
+    devs = (I32 * members)(*([0] * members))
+    assert lib.mpcx_group_init(devs, I32(members), ctypes.byref(g)) == 0, lib.mpcx_last_error(None)
+    try:
+        assert lib.mpcx_group_size(g) == members
+        rng = np.random.default_rng(r * 31 + members)
+        X0, X1, Y0, Y1 = (rng.integers(-2 ** 63, 2 ** 63, k, dtype=np.int64) for k in (r * l, r * l, l * c, l * c))
+        Z = np.zeros(r * c, dtype=np.int64)
+        rc = lib.mpcx_group_aby3_matmul_local(g, ptr(X0), ptr(X1), ptr(Y0), ptr(Y1), U64(r), U64(l), U64(c), I32(layout),
+                                              U64(KEY01), U64(11), U64(KEY20), U64(7), ptr(Z))
+        assert rc == 0, lib.mpcx_group_last_error(g)
+        assert np.array_equal(Z, orc.aby3_matmul_local(X0, X1, Y0, Y1, r, l, c, layout, KEY01, 11, KEY20, 7))
+    finally:
+        lib.mpcx_group_shutdown(g)
+
+
+def test_group_for_each_ranges(lib):
+    """The planner cuts [0, n) into contiguous multiples of the granule, and every member's callback sees its range."""
+    g = ctypes.c_void_p()
+    assert lib.mpcx_group_init((I32 * 3)(0, 0, 0), I32(3), ctypes.byref(g)) == 0
+    seen = []
+    FN = ctypes.CFUNCTYPE(I32, ctypes.c_void_p, I32, U64, U64, ctypes.c_void_p)
+
+    def cb(ctx, member, first, count, user):
+        seen.append((member, first, count, ctx == lib.mpcx_group_ctx(g, member)))
+        return 0
+
+    try:
+        for n, gran in ((1000, 64), (64, 64), (1, 64), (130, 1), (0, 64)):
+            seen.clear()
+            assert lib.mpcx_group_for_each(g, U64(n), U64(gran), FN(cb), None) == 0
+            got = sorted(seen)
+            assert all(ok for *_, ok in got)
+            assert got[0][1] == 0 and sum(c for _, _, c, _ in got) == n
+            for (_, f0, c0, _), (_, f1, _, _) in zip(got, got[1:]):
+                assert f0 + c0 == f1 and f1 % gran == 0
+        failing = FN(lambda ctx, member, first, count, user: 1 if member == 1 else 0)
+        assert lib.mpcx_group_for_each(g, U64(1000), U64(64), failing, None) != 0
+    finally:
+        lib.mpcx_group_shutdown(g)
+
+
+def kat_lines(env):
+    exe = os.path.join(HOST, "host_selftest")
+    assert os.path.exists(exe), "mpc_amd/host/host_selftest missing: run __graft_entry__.build()"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    return sorted(l for l in r.stdout.splitlines() if re.match(r"KAT ", l))
+
+
+def test_host_engines_over_a_group_give_the_same_shares():
+    """The C++ engines' own test program with MPCX_DEVICES=0,0 (ABY3 matrix_mul in row blocks, add_prepare / msb /
+    bit_inject in element ranges over two contexts): every assertion holds and every share checksum is the one of
+    the single-context run."""
+    one = kat_lines({"MPCX_DEVICES": ""})
+    two = kat_lines({"MPCX_DEVICES": "0,0"})
+    three = kat_lines({"MPCX_DEVICES": "0,0,0"})
+    assert one and one == two == three
+
+
+def test_host_benchmark_over_a_group_verifies():
+    """benchmark1's ABY3 lines (512 x 512 matrix_mul + trunc in row blocks, a 100 000-element ReLU chain in ranges)
+    over two contexts: the program checks every result against the plain computation."""
+    exe = os.path.join(HOST, "benchmark1")
+    assert os.path.exists(exe), "mpc_amd/host/benchmark1 missing: run __graft_entry__.build()"
+    r = subprocess.run([exe, "--engine", "aby3", "--width", "512", "--vec", "100000", "--repeat", "1", "--no-mlp"],
+                       capture_output=True, text=True, timeout=600, env=dict(os.environ, MPCX_DEVICES="0,0"))
+    assert r.returncode == 0 and "all results verified" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
