@@ -29,7 +29,6 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 from mpc_amd.sharding import aby3_matmul_pop_plan, matmul_row_block, split_range  # noqa: E402
 
@@ -42,10 +41,14 @@ def pair_seed(a, b):
     return {frozenset((0, 1)): KEY01, frozenset((1, 2)): KEY12, frozenset((0, 2)): KEY20}[frozenset((a, b))]
 
 
+PMC_SUMMARY = "profiles/r2_pmc_summary.json"
+PMC_BITWISE = "profiles/r2_pmc_bitwise.json"
+
+
 def measured_traffic(n, world, kernel="limb_gemm_kernel"):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE doubled
     as gfx950 requires, + WRITE_SIZE); they were taken on the default single-GPU workload only."""
-    path = os.path.join(ROOT, "profiles", "r1_pmc_summary.json")
+    path = os.path.join(ROOT, PMC_SUMMARY)
     if n != 4096 or world != 1 or not os.path.exists(path):
         return None
     d = json.load(open(path)).get(kernel)
@@ -185,6 +188,7 @@ class Aby3MatmulJob:
 def cpu_baseline(n=2048):
     """The CPU oracle (a port of the reference algorithm) on the same workload at a bounded size: three
     party threads, each single-threaded, as the reference runs three single-threaded processes."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))  # the oracle backend is test infrastructure: cpu_baseline leg only
     from backends import OracleBackend
     from oracle_lib import prg_pops
     orc = OracleBackend()
@@ -232,7 +236,8 @@ def cpu_bitwise(log2n=18):
     """The CPU oracle on the privateCompare / msb / ReLU items at a bounded size (they are O(n)): one thread plays
     every role in turn, as bitwise_rates does on the GPU.  Inputs as there (privateCompare: r = -1 on every fifth
     element; msb: pop / 2; ReLU: pops)."""
-    import protocols as pr
+    sys.path.insert(0, os.path.join(ROOT, "tests"))  # the oracle backend is test infrastructure: cpu_baseline leg only
+    import mpc_amd.protocols as pr
     from backends import OracleBackend
     orc = OracleBackend()
     n = 1 << log2n
@@ -304,8 +309,8 @@ def bitwise_rates(ctx, torch, dev, log2n=24, rank=0, world=1):
     items split a vector of 2^log2n elements (its buffer offsets reach 256 * n_total words of a serial generator,
     and walking those once per rank is set-up time that would dominate this script if n_total grew with the ranks);
     the ABY3 chain, which only pops, gives every rank 2^log2n elements of a vector of world * 2^log2n."""
-    import protocols as pr
-    from backends import ResidentBackend
+    import mpc_amd.protocols as pr
+    from mpc_amd.backends import ResidentBackend
     be = ResidentBackend(ctx, torch, dev)
     GiB = 1 << 30
     nt = 1 << log2n                      # SecureNN: the whole vector
@@ -325,17 +330,39 @@ def bitwise_rates(ctx, torch, dev, log2n=24, rank=0, world=1):
     [t.start() for t in walks]
     [t.join() for t in walks]
     out["ckpt_build_s"] = round(time.perf_counter() - t0, 2)
-    xb = torch.randint(0, 67, (64 * n,), dtype=torch.int16, device=dev)
-    beta = torch.randint(0, 2, (n,), dtype=torch.int8, device=dev)
-    r = torch.randint(-2 ** 62, 2 ** 62, (n,), dtype=torch.int64, device=dev)
-    r[2::5] = -1  # test/test_securenn.cpp:165-166
+    # Inputs as test/test_securenn.cpp:160-175 draws them from PRgenerator(22,0), 67 pops per element: x, r (forced to
+    # -1 when i % 5 == 2), beta = the low bit of a pop, then for every bit position k the share xs0[k] = (uint16)pop % 67
+    # of party 0; party 1's share (bit_k(x) + 67 - xs0[k]) % 67 is what the party role of party 1 would be handed.
+    t0 = time.perf_counter()
+    ctx.call("prg_ckpt_build", 22, 0, 67 * nt, 0)
+    out["input_ckpt_build_s"] = round(time.perf_counter() - t0, 2)
+    xb = torch.empty(64 * n, dtype=torch.int16, device=dev)
+    xb1 = torch.empty(64 * n, dtype=torch.int16, device=dev)
+    beta = torch.empty(n, dtype=torch.int8, device=dev)
+    r = torch.empty(n, dtype=torch.int64, device=dev)
+    step = 1 << 18
+    kk = torch.arange(64, device=dev)
+    for a in range(0, n, step):
+        m = min(step, n - a)
+        w = torch.empty(67 * m, dtype=torch.int64, device=dev)
+        ctx.call("prg_fill_pop", 22, 0, 67 * (i0 + a), 67 * m, w)
+        w = w.view(m, 67)
+        x = w[:, 0]
+        r[a:a + m] = w[:, 1]
+        beta[a:a + m] = (w[:, 2] & 1).to(torch.int8)
+        s0 = (w[:, 3:] & 0xFFFF) % 67
+        xb[64 * a:64 * (a + m)] = s0.to(torch.int16).reshape(-1)
+        xb1[64 * a:64 * (a + m)] = ((((x.unsqueeze(1) >> kk) & 1) + 67 - s0) % 67).to(torch.int16).reshape(-1)
+    idx = torch.arange(i0, i0 + n, device=dev)
+    r[idx % 5 == 2] = -1  # test/test_securenn.cpp:165-166
+    del w, x, s0, idx
     d0 = torch.empty(64 * n, dtype=torch.int16, device=dev)
     d1 = torch.empty(64 * n, dtype=torch.int16, device=dev)
     b2 = torch.empty(n, dtype=torch.int8, device=dev)
     for label, cap in (("cold", 0), ("warm", 8 * GiB)):
         ctx.call("set_rand_cache", cap)
         ctx.call("snn_pc_party", 0, xb, beta, r, nt, i0, n, KEY01, d0)
-        ctx.call("snn_pc_party", 1, xb, beta, r, nt, i0, n, KEY01, d1)
+        ctx.call("snn_pc_party", 1, xb1, beta, r, nt, i0, n, KEY01, d1)
         ctx.call("profile", 1)
         dt, _ = _timed(torch, lambda: ctx.call("snn_pc_party", 0, xb, beta, r, nt, i0, n, KEY01, d0), reps=3)
         ms, cnt = prof_read(ctx, "pc_party")
@@ -346,7 +373,14 @@ def bitwise_rates(ctx, torch, dev, log2n=24, rank=0, world=1):
         out[f"pc_party_{label}_prg_ms"] = round(msp / 3, 3)
     dt, _ = _timed(torch, lambda: ctx.call("snn_pc_helper", d0, d1, n, b2), reps=3)
     rate("pc_helper_elems_per_s", n, dt)
-    del xb, d0, d1, b2, beta, r
+    # the recipe's own check (test/test_securenn.cpp:201-209): beta xor beta' = (x > r) unsigned, on the first chunk
+    m = min(n, 1 << 18)
+    w = torch.empty(67 * m, dtype=torch.int64, device=dev)
+    ctx.call("prg_fill_pop", 22, 0, 67 * i0, 67 * m, w)
+    x = w.view(m, 67)[:, 0]
+    top = torch.iinfo(torch.int64).min
+    assert torch.equal((beta[:m] ^ b2[:m]).bool(), (x ^ top) > (r[:m] ^ top)), "privateCompare: beta ^ beta' != (x > r)"
+    del xb, xb1, d0, d1, b2, beta, r, w, x
 
     # ---- SecureNN msb, whole protocol (test/test_securenn.cpp:283-308: a = pop_int64() / 2)
     a = torch.empty(n, dtype=torch.int64, device=dev)
@@ -404,8 +438,8 @@ def bitwise_rates(ctx, torch, dev, log2n=24, rank=0, world=1):
     # ---- MyEngine ReLU chain (test/test_Myengine.cpp, benchmark/benchmark1.cpp:180-204): msb -> bit_inject -> subtract,
     # parties 0 / 1 and the dealer on this GPU; the drivers take whole vectors, so it runs on one rank only
     if world == 1:
-        import my_protocols as mp
-        from my_backends import GpuMy
+        import mpc_amd.my_protocols as mp
+        from mpc_amd.my_backends import GpuMy
 
         class ResidentMy(ResidentBackend, GpuMy):
             pass
@@ -449,15 +483,20 @@ def merge_bitwise(per_rank):
         slowest = max(d["_counts"][key] / d[key] for d in per_rank)
         out[key] = sum(d["_counts"][key] for d in per_rank) / slowest
     g = len(per_rank)
-    # per-GPU HBM rates: 265 B/elem of protocol data + the 64 cached s bytes (u is only read when beta = 1 and
-    # r = -1) for the party role, 257 B/elem for the helper role
-    out["pc_party_warm_GBps_per_gpu"] = (265.0 + 64.0) * out["pc_party_warm_elems_per_s"] / g / 1e9
-    out["pc_party_warm_hbm_frac"] = out["pc_party_warm_GBps_per_gpu"] / HBM_PEAK_GBS
+    # per-GPU HBM rates on the algorithmic bytes of each item: privateCompare party role 265 B/elem (128 x-bit shares +
+    # 8 r + 1 beta in, 128 d out; the s / u bytes come from the generator), helper role 257 B/elem; ABY3 ReLU chain
+    # 380 B/elem and party (16 in + 16 out + the bytes the party sends and receives: 182 + 166, 182 + 166, 158 + 190),
+    # three parties per element on this GPU
+    for label in ("cold", "warm"):
+        out[f"pc_party_{label}_GBps_per_gpu"] = 265.0 * out[f"pc_party_{label}_elems_per_s"] / g / 1e9
+        out[f"pc_party_{label}_hbm_frac"] = out[f"pc_party_{label}_GBps_per_gpu"] / HBM_PEAK_GBS
     out["pc_helper_GBps_per_gpu"] = 257.0 * out["pc_helper_elems_per_s"] / g / 1e9
     out["pc_helper_hbm_frac"] = out["pc_helper_GBps_per_gpu"] / HBM_PEAK_GBS
+    out["aby3_relu_GBps_per_gpu"] = 3 * 380.0 * out["aby3_relu_elems_per_s"] / g / 1e9
+    out["aby3_relu_hbm_frac"] = out["aby3_relu_GBps_per_gpu"] / HBM_PEAK_GBS
     out["ranks"] = g
     # HBM bytes per launch from the committed rocprofv3 --pmc passes (taken at 2^24 elements on one GPU)
-    path = os.path.join(ROOT, "profiles", "r1_pmc_bitwise.json")
+    path = os.path.join(ROOT, PMC_BITWISE)
     if g == 1 and out.get("n") == 1 << 24 and os.path.exists(path):
         pmc = json.load(open(path))
         for k in ("pc_party_kernel", "pc_helper_kernel"):
@@ -568,6 +607,10 @@ def main():
         avg_s = gemm_ms / gemm_cnt * 1e-3
         achieved = ops_per_product * 3 * args.steps / (gemm_ms * 1e-3) / 1e12
         issued = achieved * nprod / 36
+        # the whole product phase: operand split + GEMM + recombination (the residue formulation pays for its 18
+        # instead of 36 products with a residue split and a CRT pass; the digit-pair formulation folds in its epilogue)
+        phase_ms = gemm_ms + breakdown["split_limbs"] * args.steps
+        phase = ops_per_product * 3 * args.steps / (phase_ms * 1e-3) / 1e12
         res = {
             "metric": "Z_2^64 share-matmul Gop/s + MSB/privateCompare elems/sec at 1/2/4/8 GPUs",
             "value": value, "unit": "Gop/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -580,12 +623,14 @@ def main():
             "roofline": {"bound": "mfma", "kernel": kernel, "achieved": achieved, "peak": INT8_PEAK_TOPS,
                          "unit": "TFLOP/s", "frac": achieved / INT8_PEAK_TOPS,
                          "issued": issued, "issued_frac": issued / INT8_PEAK_TOPS, "int8_products_per_multiply_add": nprod,
+                         "gemm_phase": phase, "gemm_phase_frac": phase / INT8_PEAK_TOPS,
                          "traffic": measured_traffic(args.size, world, kernel),
-                         "traffic_unit": "bytes per launch (profiles/r1_pmc_summary.json)",
+                         "traffic_unit": f"bytes per launch ({PMC_SUMMARY})",
                          "avg_launch_ms": avg_s * 1e3, "launches": gemm_cnt,
                          "note": "achieved = algorithmic int8 TOP/s: 36 digit pairs x 2 x rows x c x 2l per product over the "
                                  "summed launch time of the GEMM kernel; issued = the int8 operations the kernel executes "
-                                 "(18 residue products instead of 36 digit-pair products when the residue formulation runs)"},
+                                 "(18 residue products instead of 36 digit-pair products when the residue formulation runs); "
+                                 "gemm_phase = the same algorithmic work over operand split + GEMM + recombination"},
             "kernel_ms_per_step": breakdown,
         }
         if bitwise is not None:
