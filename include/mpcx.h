@@ -259,6 +259,30 @@ int mpcx_snn_msbl1_party_mid(mpcx_ctx *ctx, int party, const int64_t *beta1_j, c
 int mpcx_snn_msbl1_party_finish(mpcx_ctx *ctx, const int64_t *gamma, const int64_t *delta, const int64_t *theta,
                                 uint64_t n, int64_t *B);
 
+/* msb (:1089-1101 = shareConvert of 2a, then msb_L_1) for parties 0 / 1 with ONE call per gap between two messenger
+ * rounds (a party that sends nothing in a round may do the work on either side of it):
+ *  party_open          before shareConvert's round 1: x_j = 2 a_j + r_j                (= ring_shl1 + sc_party_open)
+ *  party_convert_open  after msb_L_1's round 1 (x_j of the deal has arrived): the end of shareConvert on 2 a_j, then
+ *                      r_j = 2 y_j +L x_j                                      (= sc_party_finish + msbl1_party_open)
+ *  party_pc_inputs     after msb_L_1's round 2, in one pass                            (= msbl1_party_pc_inputs)
+ *  party_mid_open      after vector_mul's round 1 (A, B of the triple have arrived): gamma_j, delta_j and the masked
+ *                      operands E, F                        (= msbl1_party_mid + beaver_party_open_vecmul)
+ *  party_finish        after vector_mul's round 2       (= beaver_party_finish_vecmul + msbl1_party_finish)
+ * A is the msb() input a_j itself (not doubled). */
+int mpcx_snn_msb_party_open(mpcx_ctx *ctx, int party, const int64_t *A, uint64_t n_total, uint64_t i0, uint64_t n,
+                            uint64_t seed01, int64_t *x_out);
+int mpcx_snn_msb_party_convert_open(mpcx_ctx *ctx, int party, const int64_t *A, const int64_t *delta_j,
+                                    const int64_t *eta1_j, const int64_t *xj, uint64_t n_total, uint64_t i0, uint64_t n,
+                                    uint64_t seed01, int64_t *r_out);
+int mpcx_snn_msb_party_pc_inputs(mpcx_ctx *ctx, const int64_t *r_own, const int64_t *r_peer, uint64_t i0, uint64_t n,
+                                 uint64_t seed01, int8_t *beta_out, int64_t *R_out);
+int mpcx_snn_msb_party_mid_open(mpcx_ctx *ctx, int party, const int64_t *beta1_j, const int64_t *xlsb_j,
+                                const int8_t *beta0, const int64_t *R, const int64_t *A, const int64_t *B, uint64_t n,
+                                int64_t *gamma_out, int64_t *delta_out, int64_t *E, int64_t *F);
+int mpcx_snn_msb_party_finish(mpcx_ctx *ctx, int party, const int64_t *A, const int64_t *B, const int64_t *C,
+                              const int64_t *E_own, const int64_t *F_own, const int64_t *E_peer, const int64_t *F_peer,
+                              const int64_t *gamma, const int64_t *delta, uint64_t n, int64_t *Bout);
+
 /* ---- MyEngine (mpc_engine/MyEngine.cpp): additive shares on parties 0/1, party 2 deals ----
  * seed0 / seed1 = the streams party 2 shares with party 0 / 1 (its prgs[0] / prgs[1], KEY20 / KEY12, :21-24);
  * seed2 = that same stream as seen from party 0 / 1 (its prgs[2]); seedS = party 2's self stream; seed01 = the

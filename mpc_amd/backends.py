@@ -311,6 +311,31 @@ class GpuBackend:
                         ("out", np.int64, n))
 
 
+    # ---- SecureNN msb, one call per messenger gap
+    def snn_msb_party_open(self, party, A, n_total, i0, seed01):
+        return self._go("snn_msb_party_open", party, _c(A, np.int64), n_total, i0, A.size, seed01, ("out", np.int64, A.size))
+
+    def snn_msb_party_convert_open(self, party, A, delta_j, eta1_j, xj, n_total, i0, seed01):
+        return self._go("snn_msb_party_convert_open", party, _c(A, np.int64), _c(delta_j, np.int64), _c(eta1_j, np.int64),
+                        _c(xj, np.int64), n_total, i0, A.size, seed01, ("out", np.int64, A.size))
+
+    def snn_msb_party_pc_inputs(self, r_own, r_peer, i0, seed01):
+        n = r_own.size
+        return self._go("snn_msb_party_pc_inputs", _c(r_own, np.int64), _c(r_peer, np.int64), i0, n, seed01,
+                        ("out", np.int8, n), ("out", np.int64, n))
+
+    def snn_msb_party_mid_open(self, party, beta1_j, xlsb_j, beta0, R, A, B):
+        n = R.size
+        return self._go("snn_msb_party_mid_open", party, _c(beta1_j, np.int64), _c(xlsb_j, np.int64), _c(beta0, np.int8),
+                        _c(R, np.int64), _c(A, np.int64), _c(B, np.int64), n, *[("out", np.int64, n)] * 4)
+
+    def snn_msb_party_finish(self, party, A, B, C, E_own, F_own, E_peer, F_peer, gamma, delta):
+        n = A.size
+        return self._go("snn_msb_party_finish", party,
+                        *[_c(x, np.int64) for x in (A, B, C, E_own, F_own, E_peer, F_peer, gamma, delta)], n,
+                        ("out", np.int64, n))
+
+
 class ResidentBackend(GpuBackend):
     """GpuBackend whose arrays stay on the device: inputs and outputs are DeviceArrays borrowed from torch's
     caching allocator, nothing is copied to the host and nothing synchronises.  Used to time whole protocols

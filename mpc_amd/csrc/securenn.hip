@@ -645,4 +645,102 @@ int mpcx_snn_msbl1_party_finish(mpcx_ctx *ctx, const int64_t *gamma, const int64
     });
 }
 
+// ---- msb (:1089-1101 = shareConvert of 2a, then msb_L_1): the local segments of parties 0 / 1 that fall into one gap
+// between two messenger rounds, as one call each.  A party that sends nothing in a round (shareConvert's round 4 into
+// msb_L_1's round 1; msb_L_1's round 4 into vector_mul's round 1) may do the work on either side of it, so the work is
+// done once both inputs are there.
+// before shareConvert's round 1 (:1094-1098, :718): x_j = 2 a_j + r_j
+int mpcx_snn_msb_party_open(mpcx_ctx *ctx, int party, const int64_t *A, uint64_t n_total, uint64_t i0, uint64_t n,
+                            uint64_t seed01, int64_t *x_out) {
+    if (n == 0) return 0;
+    MPCX_REQUIRE(party == 0 || party == 1, "mpcx_snn_msb_party_open: party %d", party);
+    MPCX_REQUIRE(A && x_out, "mpcx_snn_msb_party_open: NULL pointer");
+    MPCX_REQUIRE(i0 + n <= n_total, "mpcx_snn_msb_party_open: range outside the vector");
+    const u64 first[2] = {i0, n_total + i0};
+    return prg_buff_map<2, u64>(
+        ctx, seed01, first, n,
+        [=] __device__(const u64(&w)[2], u32) {
+            const ScRand s = sc_rand(w[0], w[1]);
+            return party == 0 ? s.r0 : s.r1;
+        },
+        [=] __device__(u64 i, u64 rj) { x_out[i] = (i64)(((u64)A[i] << 1) + rj); });
+}
+// after msb_L_1's round 1: the end of shareConvert (:750-765, on the 2 a_j of :1094-1098) and r_j = 2 y_j + x_j over
+// Z_{2^64-1} (:1004-1005)
+int mpcx_snn_msb_party_convert_open(mpcx_ctx *ctx, int party, const int64_t *A, const int64_t *delta_j,
+                                    const int64_t *eta1_j, const int64_t *xj, uint64_t n_total, uint64_t i0, uint64_t n,
+                                    uint64_t seed01, int64_t *r_out) {
+    if (n == 0) return 0;
+    MPCX_REQUIRE(party == 0 || party == 1, "mpcx_snn_msb_party_convert_open: party %d", party);
+    MPCX_REQUIRE(A && delta_j && eta1_j && xj && r_out, "mpcx_snn_msb_party_convert_open: NULL pointer");
+    MPCX_REQUIRE(i0 + n <= n_total, "mpcx_snn_msb_party_convert_open: range outside the vector");
+    const u64 pid = (u64)party;
+    const u64 first[2] = {i0, n_total + i0};
+    return prg_buff_map<2, ScPick>(
+        ctx, seed01, first, n,
+        [=] __device__(const u64(&w)[2], u32 eta2) {
+            const ScRand s = sc_rand(w[0], w[1]);
+            return ScPick{party == 0 ? s.r0 : s.r1, (u64)(s.R < s.r0) | (u64)eta2 << 1};
+        },
+        [=] __device__(u64 i, ScPick v) {
+            const u64 rj = v.rj, alpha = v.bits & 1, eta2 = v.bits >> 1;
+            const u64 a = (u64)A[i] << 1, x = a + rj;
+            const u64 beta = x < rj;
+            u64 eta = add_L_1((u64)eta1_j[i], pid * eta2);
+            const u64 t = add_L_1((u64)eta1_j[i], (u64)eta1_j[i]) * eta2;
+            eta = sub_L_1(eta, t);
+            u64 theta = add_L_1(beta, (1 - pid) * (L_1 - 1 - alpha));
+            theta = add_L_1(theta, eta);
+            theta = add_L_1(theta, (u64)delta_j[i]);
+            const u64 y = sub_L_1(a, theta);                          // :765
+            r_out[i] = (i64)add_L_1(add_L_1(y, y), (u64)xj[i]);       // :1004-1005
+        });
+}
+// after msb_L_1's round 2 (:985, :1013): beta = bool_buff01[i0 + i], R = r_peer +L r_own, in one pass
+int mpcx_snn_msb_party_pc_inputs(mpcx_ctx *ctx, const int64_t *r_own, const int64_t *r_peer, uint64_t i0, uint64_t n,
+                                 uint64_t seed01, int8_t *beta_out, int64_t *R_out) {
+    if (n == 0) return 0;
+    MPCX_REQUIRE(r_own && r_peer && beta_out && R_out, "mpcx_snn_msb_party_pc_inputs: NULL pointer");
+    const u64 first[1] = {i0};
+    return prg_buff_map<1, u64>(
+        ctx, seed01, first, n, [] __device__(const u64(&)[1], u32 b) { return (u64)b; },
+        [=] __device__(u64 i, u64 b) {
+            beta_out[i] = (i8)b;
+            R_out[i] = (i64)add_L_1((u64)r_peer[i], (u64)r_own[i]);
+        });
+}
+// after vector_mul's round 1 (the triple has arrived): gamma_j, delta_j of :1025-1031 and the masked operands
+// E = gamma - A, F = delta - B of vector_mul (:253-262)
+int mpcx_snn_msb_party_mid_open(mpcx_ctx *ctx, int party, const int64_t *beta1_j, const int64_t *xlsb_j,
+                                const int8_t *beta0, const int64_t *R, const int64_t *A, const int64_t *B, uint64_t n,
+                                int64_t *gamma_out, int64_t *delta_out, int64_t *E, int64_t *F) {
+    MPCX_REQUIRE(party == 0 || party == 1, "mpcx_snn_msb_party_mid_open: party %d", party);
+    MPCX_REQUIRE((beta1_j && xlsb_j && beta0 && R && A && B && gamma_out && delta_out && E && F) || n == 0,
+                 "mpcx_snn_msb_party_mid_open: NULL pointer");
+    const u64 pid = (u64)party;
+    return ew_launch(ctx, n, [=] __device__(u64 i) {
+        const u64 r0 = (u64)R[i] % 2, b0 = (u64)(i64)beta0[i];
+        const u64 g = (u64)beta1_j[i] + pid * b0 - 2 * b0 * (u64)beta1_j[i];
+        const u64 d = (u64)xlsb_j[i] + pid * r0 - 2 * r0 * (u64)xlsb_j[i];
+        gamma_out[i] = (i64)g;
+        delta_out[i] = (i64)d;
+        E[i] = (i64)(g - (u64)A[i]);
+        F[i] = (i64)(d - (u64)B[i]);
+    });
+}
+// after vector_mul's round 2: theta_j (:294) and b_j = gamma_j + delta_j - 2 theta_j (:1036)
+int mpcx_snn_msb_party_finish(mpcx_ctx *ctx, int party, const int64_t *A, const int64_t *B, const int64_t *C,
+                              const int64_t *E_own, const int64_t *F_own, const int64_t *E_peer, const int64_t *F_peer,
+                              const int64_t *gamma, const int64_t *delta, uint64_t n, int64_t *Bout) {
+    MPCX_REQUIRE(party == 0 || party == 1, "mpcx_snn_msb_party_finish: party %d", party);
+    MPCX_REQUIRE((A && B && C && E_own && F_own && E_peer && F_peer && gamma && delta && Bout) || n == 0,
+                 "mpcx_snn_msb_party_finish: NULL pointer");
+    const u64 pid = (u64)party;
+    return ew_launch(ctx, n, [=] __device__(u64 i) {
+        const u64 Ev = (u64)E_own[i] + (u64)E_peer[i], Fv = (u64)F_own[i] + (u64)F_peer[i];
+        const u64 theta = (u64)C[i] + Ev * (u64)B[i] + Fv * (u64)A[i] + Fv * Ev * pid;
+        Bout[i] = (i64)((u64)gamma[i] + (u64)delta[i] - 2 * theta);
+    });
+}
+
 } // extern "C"

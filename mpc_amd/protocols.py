@@ -277,7 +277,58 @@ def snn_msb_L1(w, Ys):
     return [B0, B1]
 
 
+SNN_FUSED = True  # drive backends that have them through the one-call-per-gap msb segments
+
+
 def snn_msb(w, As):
     """msb (SecurennEngine.cpp:1089-1101): shareConvert(2a) then msb_L_1."""
+    if SNN_FUSED and hasattr(w.be, "snn_msb_party_open"):
+        return snn_msb_fused(w, As)
     twoA = [w.be.ring_shl1(As[0]), w.be.ring_shl1(As[1])]
     return snn_msb_L1(w, snn_share_convert(w, twoA))
+
+
+def snn_msb_fused(w, As):
+    """The same rounds and messages as snn_msb, with the local work of parties 0 / 1 done as one call per gap between
+    two messenger rounds (the message tags are those of the separate segments, so the logs compare one to one)."""
+    be = w.be
+    n = As[0].size
+    nt, i0 = w.whole(n), w.i0
+    # shareConvert (SecurennEngine.cpp:685-893) on 2a
+    x0 = be.snn_msb_party_open(0, As[0], nt, i0, KEY01)
+    x1 = be.snn_msb_party_open(1, As[1], nt, i0, KEY01)
+    w.rec("sc.x0", x0)
+    w.rec("sc.x1", x1)
+    xb0, dl0, xb1, dl1 = be.snn_sc_helper_split(x0, x1, nt, i0, KEYS)
+    for tag, m in (("xb0", xb0), ("dl0", dl0), ("xb1", xb1), ("dl1", dl1)):
+        w.rec("sc.P2." + tag, m)
+    eta2, rm1 = be.snn_sc_party_pc_inputs(nt, i0, n, KEY01)
+    eta1 = snn_private_compare(w, [xb0, xb1], eta2, rm1)
+    e0, e1 = be.snn_sc_helper_eta(eta1, nt, i0, KEYS)
+    w.rec("sc.P2.eta0", e0)
+    w.rec("sc.P2.eta1", e1)
+    # msb_L_1 (:898-1084)
+    X0, l0, xbb0, X1, l1, xbb1 = be.snn_msbl1_helper_deal(nt, i0, n, KEYS)
+    for tag, m in (("x0", X0), ("l0", l0), ("xb0", xbb0), ("x1", X1), ("l1", l1), ("xb1", xbb1)):
+        w.rec("msbl1.P2." + tag, m)
+    r0 = be.snn_msb_party_convert_open(0, As[0], dl0, e0, X0, nt, i0, KEY01)
+    r1 = be.snn_msb_party_convert_open(1, As[1], dl1, e1, X1, nt, i0, KEY01)
+    w.rec("msbl1.r0", r0)
+    w.rec("msbl1.r1", r1)
+    beta0, R = be.snn_msb_party_pc_inputs(r0, r1, i0, KEY01)
+    if w.record:  # party 1 derives the same pair
+        beta0b, Rb = be.snn_msb_party_pc_inputs(r1, r0, i0, KEY01)
+        assert np.array_equal(R, Rb) and np.array_equal(beta0, beta0b)
+    beta1 = snn_private_compare(w, [xbb0, xbb1], beta0, R)
+    b0, b1 = be.snn_msbl1_helper_beta(beta1, nt, i0, KEYS)
+    w.rec("msbl1.P2.b0", b0)
+    w.rec("msbl1.P2.b1", b1)
+    A0, B0, C0, A1, B1, C1 = be.snn_beaver_dealer_vecmul(KEYS, nt, i0, n)
+    for tag, m in (("A0", A0), ("B0", B0), ("C0", C0), ("A1", A1), ("B1", B1), ("C1", C1)):
+        w.rec("snn_vecmul.P2." + tag, m)
+    g0, d0, E0, F0 = be.snn_msb_party_mid_open(0, b0, l0, beta0, R, A0, B0)
+    g1, d1, E1, F1 = be.snn_msb_party_mid_open(1, b1, l1, beta0, R, A1, B1)
+    for tag, m in (("E0", E0), ("F0", F0), ("E1", E1), ("F1", F1)):
+        w.rec("snn_vecmul." + tag, m)
+    return [be.snn_msb_party_finish(0, A0, B0, C0, E0, F0, E1, F1, g0, d0),
+            be.snn_msb_party_finish(1, A1, B1, C1, E1, F1, E0, F0, g1, d1)]

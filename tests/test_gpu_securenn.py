@@ -142,9 +142,11 @@ def test_snn_matmul_protocol_parity(gpu, orc, r, l, c, layout):
     assert np.array_equal(tr(pr.snn_reveal(wg, Zg), r, c), orc.ring_gemm(X, Y, r, l, c))
 
 
+@pytest.mark.parametrize("fused", [True, False])  # parties 0 / 1 with one call per messenger gap, or segment by segment
 @pytest.mark.parametrize("n", [1, 10, 1000, 2000, (1 << 20) + 77])  # the last: every kernel grid-strides
-def test_snn_msb_parity(gpu, orc, n):
+def test_snn_msb_parity(gpu, orc, n, fused, monkeypatch):
     """n = 2000 is the reference benchmark's size, which the reference itself cannot run (buffer overrun)."""
+    monkeypatch.setattr(pr, "SNN_FUSED", fused)
     a = trunc_div2(prg_pops(22, 67 * 1000, n))
     res = []
     for be in (gpu, orc):
