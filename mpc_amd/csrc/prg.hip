@@ -266,25 +266,6 @@ __global__ __launch_bounds__(256) void prg_fill_kernel(const PrgCk *__restrict__
 // out[i] = (uint16)int_buff[first + i] % 67 (0 -> 1 when zero_to_one) for a run whose first stream word is a
 // checkpoint: a lane's PRG_CK stream words are PRG_CK / 2 consecutive output bytes, which it packs in registers and
 // stores itself -- no exchange through LDS, no work on the discarded odd words beyond the generator step.
-// PRG_CK / 2 bytes (uint16)int_buff % 67 from one checkpoint, packed four to a word
-__device__ inline void mod67_run(const PrgCk c, int zero_to_one, u32 (&w)[PRG_CK / 8]) {
-    u64 seed = c.seed, lcg = c.lcg, hash = c.hash;
-#pragma unroll
-    for (u32 q = 0; q < PRG_CK / 8; q++) {
-        u32 acc = 0;
-#pragma unroll
-        for (u32 k = 0; k < 4; k++) {
-            const u32 x = (u32)prv_step(seed, lcg, hash) & 0xFFFFu;
-            (void)prv_step(seed, lcg, hash);
-            // x % 67 for x < 2^16: floor(x / 67) = (x * 62602) >> 22 exactly, in 24-bit multiplies
-            u32 m = x - (u32)__umul24((u32)__umul24(x, 62602u) >> 22, 67u);
-            if (zero_to_one && m == 0) m = 1;
-            acc |= m << (8 * k);
-        }
-        w[q] = acc;
-    }
-}
-
 __global__ __launch_bounds__(256) void prg_mod67_kernel(const PrgCk *__restrict__ ck, u64 seg0, u64 count, int zero_to_one,
                                                         u8 *__restrict__ out) {
     constexpr u32 BPL = PRG_CK / 2; // bytes per lane

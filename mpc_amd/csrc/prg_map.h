@@ -31,6 +31,25 @@ __host__ __device__ inline u64 prv_step(u64 &seed, u64 &lcg, u64 &hash) {
     return lcg ^ rs;
 }
 
+// PRG_CK / 2 bytes (uint16)int_buff % 67 from one checkpoint, packed four to a word
+__device__ inline void mod67_run(const PrgCk c, int zero_to_one, u32 (&w)[PRG_CK / 8]) {
+    u64 seed = c.seed, lcg = c.lcg, hash = c.hash;
+#pragma unroll
+    for (u32 q = 0; q < PRG_CK / 8; q++) {
+        u32 acc = 0;
+#pragma unroll
+        for (u32 k = 0; k < 4; k++) {
+            const u32 x = (u32)prv_step(seed, lcg, hash) & 0xFFFFu;
+            (void)prv_step(seed, lcg, hash);
+            // x % 67 for x < 2^16: floor(x / 67) = (x * 62602) >> 22 exactly, in 24-bit multiplies
+            u32 m = x - (u32)__umul24((u32)__umul24(x, 62602u) >> 22, 67u);
+            if (zero_to_one && m == 0) m = 1;
+            acc |= m << (8 * k);
+        }
+        w[q] = acc;
+    }
+}
+
 // f(rel, v) for rel in [0, count) with v = g(A[tA + rel], B[tB + rel]) (TWO streams) or v = A[tA + rel] (one).
 // g runs in the producing lane (registers only); f runs in memory order.  A lane starts from the checkpoint below
 // its first word and discards the words in between (the same number for every lane).

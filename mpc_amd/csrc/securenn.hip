@@ -106,62 +106,103 @@ __device__ inline void pc_piece(u32 pid, int mode, u32 q, u32 bits8, const u32 (
     }
 }
 
+// One piece (8 bit positions of element c >> 3) from its loads to its store; load_sb() = the 8 s bytes of the piece.
+template <class SB>
+__device__ inline void pc_party_lane(u32 pid, int variant, bool live, u64 c, const uint4 *__restrict__ xbits,
+                                     const i8 *__restrict__ beta, const i64 *__restrict__ r, SB load_sb,
+                                     const u64 *__restrict__ U, uint4 *__restrict__ d_out) {
+    const u64 i = live ? c >> 3 : 0;
+    const u32 q = (u32)(c & 7);
+    u32 xw[4] = {0, 0, 0, 0}, dw[4] = {0, 0, 0, 0};
+    uint2 sb = make_uint2(0, 0);
+    u64 rv = 0;
+    int bt = 0;
+    if (live) {
+        const uint4 xv = ld_stream(xbits + c);
+        xw[0] = xv.x, xw[1] = xv.y, xw[2] = xv.z, xw[3] = xv.w;
+        sb = load_sb();
+        rv = (u64)r[i];
+        bt = beta[i];
+    }
+    const int mode = (bt == 0) ? 0 : ((variant == 1 || (bt == 1 && rv != ~0ull)) ? 1 : 2);
+    // the 8 bits of r (mode 0) or r + 1 (mode 1) this lane works on
+    const u32 bits8 = (u32)(((mode == 0 ? rv : rv + 1) >> (8 * q)) & 0xFF);
+    // any 16-bit x above 66?  (above 127, or below 128 with x + 61 reaching 128)
+    u32 big = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) big |= (xw[k] & 0xFF80FF80u) | ((xw[k] + 0x003D003Du) & 0x00800080u);
+    if (__any(big != 0))
+        pc_piece<false>(pid, mode, q, bits8, xw, sb, dw);
+    else
+        pc_piece<true>(pid, mode, q, bits8, xw, sb, dw);
+    if (__any(mode == 2)) { // beta = 1 and r = -1 (:574-584): c comes from u alone
+        uint2 ub = make_uint2(0, 0);
+        if (mode == 2 && live) ub = ((const uint2 *)U)[c];
+        u32 d2[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const u32 uk = ((j < 4 ? ub.x : ub.y) >> (8 * (j & 3))) & 0xFF;
+            // :577-578: (1 - party)(1 + u) + (67 - party) u stays below 2^16 for u < 67, so it is 1 + 68 u = 1 + u
+            // (party 0) or 66 u = -u (party 1) mod 67; the generated u bytes are in [1, 66].  Position 0 (:582): u, -u.
+            u32 ck;
+            if (pid == 0)
+                ck = (q != 0 || j != 0) ? (uk == P - 1 ? 0 : uk + 1) : uk;
+            else
+                ck = P - uk;
+            const u32 sk = ((j < 4 ? sb.x : sb.y) >> (8 * (j & 3))) & 0xFF;
+            d2[j >> 1] |= mod67_u16(mul24(sk, ck)) << (16 * (j & 1));
+        }
+        if (mode == 2) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) dw[k] = d2[k];
+        }
+    }
+    if (live) st_stream(d_out + c, dw[0], dw[1], dw[2], dw[3]);
+}
+
+// s bytes read from memory (the context's cache of generator bytes, or scratch)
 __global__ __launch_bounds__(256) void pc_party_kernel(int party, int variant, const uint4 *__restrict__ xbits, const i8 *__restrict__ beta,
                                                        const i64 *__restrict__ r, const u64 *__restrict__ S,
                                                        const u64 *__restrict__ U, u64 n, uint4 *__restrict__ d_out) {
     const u64 pieces = n * 8;
     const u64 stride = (u64)gridDim.x * 256;
-    const u32 pid = (u32)party;
     for (u64 base = (u64)blockIdx.x * 256; base < pieces; base += stride) {
         const u64 c = base + threadIdx.x; // pieces is a multiple of 8, so groups of 8 lanes are all-live or all-dead
         const bool live = c < pieces;
-        const u64 i = live ? c >> 3 : 0;
-        const u32 q = (u32)(c & 7);
-        u32 xw[4] = {0, 0, 0, 0}, dw[4] = {0, 0, 0, 0};
-        uint2 sb = make_uint2(0, 0); // the 8 s bytes of this lane's positions
-        u64 rv = 0;
-        int bt = 0;
-        if (live) {
-            const uint4 xv = ld_stream(xbits + c);
-            xw[0] = xv.x, xw[1] = xv.y, xw[2] = xv.z, xw[3] = xv.w;
-            sb = ((const uint2 *)S)[c];
-            rv = (u64)r[i];
-            bt = beta[i];
+        pc_party_lane((u32)party, variant, live, c, xbits, beta, r, [&] { return ((const uint2 *)S)[c]; }, U, d_out);
+    }
+}
+
+// s bytes made on the spot (:523, :525-529 with int_buff regenerated from the stream's checkpoints): a wavefront takes
+// 32 elements at a time.  Its 64 lanes first replay one checkpoint run each -- 32 of the (uint16)int_buff % 67 bytes,
+// half an element -- into the wavefront's 2 KiB of LDS, then work through the 32 elements in four rounds of eight
+// elements x eight pieces, each lane picking its piece's 8 bytes out of LDS.  One pass over the 265 bytes of an
+// element, no s bytes in memory; ck0 = the checkpoint of element 0's first run.
+__global__ __launch_bounds__(256) void pc_party_gen_kernel(int party, int variant, const uint4 *__restrict__ xbits,
+                                                           const i8 *__restrict__ beta, const i64 *__restrict__ r,
+                                                           const PrgCk *__restrict__ ck0, const u64 *__restrict__ U, u64 n,
+                                                           uint4 *__restrict__ d_out) {
+    static_assert(PRG_CK == 64, "an element's 64 bytes are two checkpoint runs");
+    __shared__ u32 sbytes[4][512];
+    const u32 lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    u32 *mine = sbytes[wid];
+    const u64 groups = (n + 31) / 32;
+    for (u64 g = (u64)blockIdx.x * 4 + wid; g < groups; g += (u64)gridDim.x * 4) {
+        const u64 e0 = g * 32;
+        u32 w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (e0 + lane / 2 < n) mod67_run(ck0[2 * e0 + lane], 1, w);
+        *(uint4 *)(mine + 8 * lane) = make_uint4(w[0], w[1], w[2], w[3]);
+        *(uint4 *)(mine + 8 * lane + 4) = make_uint4(w[4], w[5], w[6], w[7]);
+        prg_wave_sync();
+#pragma unroll 1
+        for (u32 sub = 0; sub < 4; sub++) {
+            const u64 c = (e0 + 8 * sub) * 8 + lane;
+            const bool live = c < n * 8;
+            // element 8 sub + lane / 8 of the group, piece lane % 8
+            pc_party_lane((u32)party, variant, live, c, xbits, beta, r,
+                          [&] { return *(const uint2 *)(mine + 2 * (64 * sub + lane)); }, U, d_out);
         }
-        const int mode = (bt == 0) ? 0 : ((variant == 1 || (bt == 1 && rv != ~0ull)) ? 1 : 2);
-        // the 8 bits of r (mode 0) or r + 1 (mode 1) this lane works on
-        const u32 bits8 = (u32)(((mode == 0 ? rv : rv + 1) >> (8 * q)) & 0xFF);
-        // any 16-bit x above 66?  (above 127, or below 128 with x + 61 reaching 128)
-        u32 big = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) big |= (xw[k] & 0xFF80FF80u) | ((xw[k] + 0x003D003Du) & 0x00800080u);
-        if (__any(big != 0))
-            pc_piece<false>(pid, mode, q, bits8, xw, sb, dw);
-        else
-            pc_piece<true>(pid, mode, q, bits8, xw, sb, dw);
-        if (__any(mode == 2)) { // beta = 1 and r = -1 (:574-584): c comes from u alone
-            uint2 ub = make_uint2(0, 0);
-            if (mode == 2 && live) ub = ((const uint2 *)U)[c];
-            u32 d2[4] = {0, 0, 0, 0};
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const u32 uk = ((j < 4 ? ub.x : ub.y) >> (8 * (j & 3))) & 0xFF;
-                // :577-578: (1 - party)(1 + u) + (67 - party) u stays below 2^16 for u < 67, so it is 1 + 68 u = 1 + u
-                // (party 0) or 66 u = -u (party 1) mod 67; the generated u bytes are in [1, 66].  Position 0 (:582): u, -u.
-                u32 ck;
-                if (pid == 0)
-                    ck = (q != 0 || j != 0) ? (uk == P - 1 ? 0 : uk + 1) : uk;
-                else
-                    ck = P - uk;
-                const u32 sk = ((j < 4 ? sb.x : sb.y) >> (8 * (j & 3))) & 0xFF;
-                d2[j >> 1] |= mod67_u16(mul24(sk, ck)) << (16 * (j & 1));
-            }
-            if (mode == 2) {
-#pragma unroll
-                for (int k = 0; k < 4; k++) dw[k] = d2[k];
-            }
-        }
-        if (live) st_stream(d_out + c, dw[0], dw[1], dw[2], dw[3]);
+        prg_wave_sync();
     }
 }
 
@@ -222,23 +263,46 @@ __global__ __launch_bounds__(256) void pc_helper_kernel(const uint4 *__restrict_
 
 // Z_67 sharing of the 64 bits of v[i] (:835-842 / :919-927): rnd = one random byte (already % 67) per bit;
 // first[i][k] = rnd, second[i][k] = (bit + 67 - rnd) % 67
+__device__ inline void bit_share_piece(u64 val, u32 q, u64 rb, u64 c, uint4 *__restrict__ first, uint4 *__restrict__ second) {
+    u16x8 a{}, b{};
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const u32 s = (u32)((rb >> (8 * j)) & 0xFF);
+        const u32 bit = (u32)((val >> (8 * q + j)) & 1);
+        a.set(j, s);
+        b.set(j, (bit + P - s) % P);
+    }
+    st_stream(first + c, a.w[0], a.w[1], a.w[2], a.w[3]);
+    st_stream(second + c, b.w[0], b.w[1], b.w[2], b.w[3]);
+}
 __global__ __launch_bounds__(256) void bit_share_kernel(const u64 *__restrict__ v, const u64 *__restrict__ rnd, u64 n,
                                                         uint4 *__restrict__ first, uint4 *__restrict__ second) {
     const u64 pieces = n * 8;
-    for (u64 c = (u64)blockIdx.x * 256 + threadIdx.x; c < pieces; c += (u64)gridDim.x * 256) {
-        const u64 val = v[c >> 3];
-        const u32 q = (u32)(c & 7);
-        const u64 rb = rnd[c];
-        u16x8 a{}, b{};
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const u32 s = (u32)((rb >> (8 * j)) & 0xFF);
-            const u32 bit = (u32)((val >> (8 * q + j)) & 1);
-            a.set(j, s);
-            b.set(j, (bit + P - s) % P);
+    for (u64 c = (u64)blockIdx.x * 256 + threadIdx.x; c < pieces; c += (u64)gridDim.x * 256)
+        bit_share_piece(v[c >> 3], (u32)(c & 7), rnd[c], c, first, second);
+}
+// the same with the random bytes made on the spot, as pc_party_gen_kernel makes its s bytes: a wavefront replays the 64
+// checkpoint runs of 32 elements into its 2 KiB of LDS, then shares the 32 words in four rounds
+__global__ __launch_bounds__(256) void bit_share_gen_kernel(const u64 *__restrict__ v, const PrgCk *__restrict__ ck0, u64 n,
+                                                            uint4 *__restrict__ first, uint4 *__restrict__ second) {
+    static_assert(PRG_CK == 64, "an element's 64 bytes are two checkpoint runs");
+    __shared__ u32 rbytes[4][512];
+    const u32 lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    u32 *mine = rbytes[wid];
+    const u64 groups = (n + 31) / 32;
+    for (u64 g = (u64)blockIdx.x * 4 + wid; g < groups; g += (u64)gridDim.x * 4) {
+        const u64 e0 = g * 32;
+        u32 w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (e0 + lane / 2 < n) mod67_run(ck0[2 * e0 + lane], 0, w);
+        *(uint4 *)(mine + 8 * lane) = make_uint4(w[0], w[1], w[2], w[3]);
+        *(uint4 *)(mine + 8 * lane + 4) = make_uint4(w[4], w[5], w[6], w[7]);
+        prg_wave_sync();
+#pragma unroll 1
+        for (u32 sub = 0; sub < 4; sub++) {
+            const u64 c = (e0 + 8 * sub) * 8 + lane;
+            if (c < n * 8) bit_share_piece(v[c >> 3], lane & 7, *(const u64 *)(mine + 2 * (64 * sub + lane)), c, first, second);
         }
-        st_stream(first + c, a.w[0], a.w[1], a.w[2], a.w[3]);
-        st_stream(second + c, b.w[0], b.w[1], b.w[2], b.w[3]);
+        prg_wave_sync();
     }
 }
 
@@ -263,6 +327,33 @@ __device__ inline ScRand sc_rand(u64 w0, u64 w1) {
 }
 
 } // namespace
+
+// Z_67 sharing of the bits of v[0 .. n) with the random bytes (uint16)int_buff[rnd_first + 64 i + k] % 67 of generator
+// (seed, 0): from the context's byte cache when it is on, otherwise made inside the sharing kernel (runs that start on a
+// checkpoint) or into scratch behind the first `ws_front` bytes of the workspace, which hold v
+static int bit_share_with_stream(mpcx_ctx *ctx, const u64 *v_in_ws, u64 ws_front, u64 seed, u64 rnd_first, u64 n, u16 *first,
+                                 u16 *second) {
+    const bool cached = ctx->rand_cap >= 64 * n;
+    if (!cached && (2 * rnd_first) % PRG_CK == 0) {
+        const PrgCk *ck;
+        MPCX_TRY(mpcx_prg_table(ctx, seed, 0, 2 * (rnd_first + 64 * n) + PRG_CK, &ck));
+        u64 grid = ceil_div(ceil_div(n, 32), 4);
+        if (grid > MPCX_MAX_GRID) grid = MPCX_MAX_GRID;
+        ProfScope ps(ctx, PROF_PRG);
+        hipLaunchKernelGGL(bit_share_gen_kernel, dim3((u32)grid), dim3(256), 0, ctx->stream, v_in_ws, ck + 2 * rnd_first / PRG_CK,
+                           n, (uint4 *)first, (uint4 *)second);
+        MPCX_LAUNCH_CHECK();
+        return 0;
+    }
+    const u8 *rnd;
+    ctx->rand_tick++;
+    // (the workspace was sized for this fallback by the caller, so the request below does not move it)
+    MPCX_TRY(prg_buff_mod67_cached(ctx, seed, 0, rnd_first, 64 * n, 0, ws_front + 64 * n, ws_front, &rnd));
+    hipLaunchKernelGGL(bit_share_kernel, dim3(grid_for(8 * n)), dim3(256), 0, ctx->stream, v_in_ws, (const u64 *)rnd, n,
+                       (uint4 *)first, (uint4 *)second);
+    MPCX_LAUNCH_CHECK();
+    return 0;
+}
 
 int snn_bit_share_launch(mpcx_ctx *ctx, const u64 *v, const u8 *rnd, u64 n, u16 *first, u16 *second) {
     hipLaunchKernelGGL(bit_share_kernel, dim3(grid_for(8 * n)), dim3(256), 0, ctx->stream, v, (const u64 *)rnd, n,
@@ -405,22 +496,37 @@ int mpcx_snn_pc_party(mpcx_ctx *ctx, int party, const uint16_t *xbits, const int
     MPCX_REQUIRE(i0 + n <= n_total, "mpcx_snn_pc_party: range outside the vector");
     MPCX_REQUIRE(((uintptr_t)xbits & 15) == 0 && ((uintptr_t)d_out & 15) == 0, "mpcx_snn_pc_party: xbits/d_out must be 16-byte aligned");
     MPCX_REQUIRE(n < (1ull << 32), "mpcx_snn_pc_party: too many elements for one call");
-    const u8 *S, *U;
+    const u8 *S = nullptr, *U;
     ctx->rand_tick++;
-    // workspace when the bytes are not cached: s, u, then the list of the elements that read u and its length
-    const u64 ws_list = 128 * n, ws_total = ws_list + 4 * n + 16;
-    int u_left = 0;
-    MPCX_TRY(prg_buff_mod67_cached(ctx, seed01, 0, 64 * i0, 64 * n, 1, ws_total, 0, &S));                              // :523,525-529
-    MPCX_TRY(prg_buff_mod67_cached(ctx, seed01, 0, 64 * n_total + 64 * i0, 64 * n, 1, ws_total, 64 * n, &U, &u_left)); // :524,530-534
-    if (u_left) {
-        // Not cached: u is only read by the elements with beta = 1 and r = -1, so only their 64 bytes are made
-        // (a generator step costs as much as the comparison itself; the s bytes are needed by every element).
-        u32 *list = (u32 *)(U - 64 * n + ws_list), *listed = list + n;
+    // With the byte cache on (the counterpart of the reference's constructor-filled int_buff) s and u are read from it.
+    // Without it the s bytes are made inside the comparison kernel and never stored; the u bytes, which only the
+    // elements with beta = 1 and r = -1 read, are made for those elements alone (a generator step costs as much as the
+    // comparison itself), into scratch: u, then the list of those elements and its length.
+    const bool cached = ctx->rand_cap >= 128 * n;
+    const u64 ws_list = 64 * n, ws_total = ws_list + 4 * n + 16;
+    if (cached) {
+        // (a slice that does not fit beside what the cache already holds for this call is made in scratch instead)
+        MPCX_TRY(prg_buff_mod67_cached(ctx, seed01, 0, 64 * i0, 64 * n, 1, 128 * n, 0, &S));                      // :523,525-529
+        MPCX_TRY(prg_buff_mod67_cached(ctx, seed01, 0, 64 * n_total + 64 * i0, 64 * n, 1, 128 * n, 64 * n, &U));  // :524,530-534
+    } else {
+        void *ws;
+        MPCX_TRY(mpcx_ws(ctx, ws_total, &ws));
+        U = (const u8 *)ws;
+        u32 *list = (u32 *)((u8 *)ws + ws_list), *listed = list + n;
         MPCX_HIP(hipMemsetAsync(listed, 0, sizeof(u32), ctx->stream));
         hipLaunchKernelGGL(pc_list_u_kernel, dim3((u32)ceil_div(n, PC_LIST_CHUNK)), dim3(256), 0, ctx->stream, beta, r, n, list,
                            listed);
         MPCX_LAUNCH_CHECK();
         MPCX_TRY(prg_fill_buff_mod67_listed(ctx, seed01, 0, 64 * n_total + 64 * i0, n, 1, list, listed, (u8 *)U));
+        const PrgCk *ck;
+        MPCX_TRY(mpcx_prg_table(ctx, seed01, 0, 2 * 64 * (i0 + n) + PRG_CK, &ck));
+        ProfScope ps(ctx, PROF_PC_PARTY);
+        u64 grid = ceil_div(ceil_div(n, 32), 4);
+        if (grid > MPCX_MAX_GRID) grid = MPCX_MAX_GRID;
+        hipLaunchKernelGGL(pc_party_gen_kernel, dim3((u32)grid), dim3(256), 0, ctx->stream, party, 0, (const uint4 *)xbits, beta,
+                           r, ck + 2 * i0, (const u64 *)U, n, (uint4 *)d_out);
+        MPCX_LAUNCH_CHECK();
+        return 0;
     }
     ProfScope ps(ctx, PROF_PC_PARTY);
     hipLaunchKernelGGL(pc_party_kernel, dim3(grid_for(8 * n)), dim3(256), 0, ctx->stream, party, 0, (const uint4 *)xbits, beta,
@@ -526,12 +632,8 @@ int mpcx_snn_sc_helper_split(mpcx_ctx *ctx, const int64_t *x0, const int64_t *x1
     MPCX_REQUIRE(x0 && x1 && xbits0 && delta0 && xbits1 && delta1, "mpcx_snn_sc_helper_split: NULL pointer");
     MPCX_REQUIRE(i0 + n <= n_total, "mpcx_snn_sc_helper_split: range outside the vector");
     MPCX_REQUIRE(((uintptr_t)xbits0 & 15) == 0 && ((uintptr_t)xbits1 & 15) == 0, "mpcx_snn_sc_helper_split: xbits must be 16-byte aligned");
-    // the cache request comes first: it may grow (and so move) the workspace the other pointers live in
-    const u8 *rnd;
-    ctx->rand_tick++;
-    MPCX_TRY(prg_buff_mod67_cached(ctx, seedS, 0, 64 * i0, 64 * n, 0, 72 * n, 8 * n, &rnd)); // :838-839
-    void *ws;
-    MPCX_TRY(mpcx_ws(ctx, 8 * n, &ws));
+    void *ws; // x, then room for the random bytes should they have to be made in scratch
+    MPCX_TRY(mpcx_ws(ctx, 72 * n, &ws));
     u64 *x = (u64 *)ws;
     const u64 *a = (const u64 *)x0, *b = (const u64 *)x1;
     const u64 first[1] = {i0};
@@ -544,10 +646,7 @@ int mpcx_snn_sc_helper_split(mpcx_ctx *ctx, const int64_t *x0, const int64_t *x1
             delta0[i] = (i64)D0;
             delta1[i] = (i64)sub_L_1(delta, D0); // :851
         })));
-    hipLaunchKernelGGL(bit_share_kernel, dim3(grid_for(8 * n)), dim3(256), 0, ctx->stream, (const u64 *)x, (const u64 *)rnd,
-                       n, (uint4 *)xbits0, (uint4 *)xbits1);
-    MPCX_LAUNCH_CHECK();
-    return 0;
+    return bit_share_with_stream(ctx, x, 8 * n, seedS, 64 * i0, n, xbits0, xbits1); // :838-839
 }
 int mpcx_snn_sc_helper_eta(mpcx_ctx *ctx, const int8_t *eta1_plain, uint64_t n_total, uint64_t i0, uint64_t n,
                            uint64_t seedS, int64_t *eta0, int64_t *eta1) {
@@ -570,11 +669,8 @@ int mpcx_snn_msbl1_helper_deal(mpcx_ctx *ctx, uint64_t n_total, uint64_t i0, uin
     MPCX_REQUIRE(x0 && xlsb0 && xbits0 && x1 && xlsb1 && xbits1, "mpcx_snn_msbl1_helper_deal: NULL pointer");
     MPCX_REQUIRE(i0 + n <= n_total, "mpcx_snn_msbl1_helper_deal: range outside the vector");
     MPCX_REQUIRE(((uintptr_t)xbits0 & 15) == 0 && ((uintptr_t)xbits1 & 15) == 0, "mpcx_snn_msbl1_helper_deal: xbits must be 16-byte aligned");
-    const u8 *rnd;
-    ctx->rand_tick++;
-    MPCX_TRY(prg_buff_mod67_cached(ctx, seedS, 0, 3 * n_total + 64 * i0, 64 * n, 0, 72 * n, 8 * n, &rnd)); // :922-923
-    void *ws;
-    MPCX_TRY(mpcx_ws(ctx, 8 * n, &ws));
+    void *ws; // x, then room for the random bytes should they have to be made in scratch
+    MPCX_TRY(mpcx_ws(ctx, 72 * n, &ws));
     u64 *xv = (u64 *)ws;
     struct Deal {
         u64 X0, X1, lsb0;
@@ -592,10 +688,7 @@ int mpcx_snn_msbl1_helper_deal(mpcx_ctx *ctx, uint64_t n_total, uint64_t i0, uin
             xlsb1[i] = (i64)((X & 1) - d.lsb0); // :918
         })));
     // :922-926: the random byte is party 1's share, party 0 gets bit + 67 - it
-    hipLaunchKernelGGL(bit_share_kernel, dim3(grid_for(8 * n)), dim3(256), 0, ctx->stream, (const u64 *)xv, (const u64 *)rnd,
-                       n, (uint4 *)xbits1, (uint4 *)xbits0);
-    MPCX_LAUNCH_CHECK();
-    return 0;
+    return bit_share_with_stream(ctx, xv, 8 * n, seedS, 3 * n_total + 64 * i0, n, xbits1, xbits0);
 }
 int mpcx_snn_msbl1_helper_beta(mpcx_ctx *ctx, const int8_t *beta1_plain, uint64_t n_total, uint64_t i0, uint64_t n,
                                uint64_t seedS, int64_t *b0, int64_t *b1) {
