@@ -117,6 +117,22 @@ def test_ring_gemm_both_formulations(gpu, orc, mode, monkeypatch):
         assert np.array_equal(gpu.ring_gemm(A, B, r, l, c), orc.ring_gemm(A, B, r, l, c))
 
 
+@pytest.mark.parametrize("knob,value", [("MPCX_GEMM_GM", "0"), ("MPCX_GEMM_GM", "-3"), ("MPCX_GEMM_GM", "1000000"),
+                                        ("MPCX_RNS_GM", "0"), ("MPCX_RNS_GM", "99"), ("MPCX_GEMM_ABLATE", "1"),
+                                        ("MPCX_GEMM_ABLATE", "3")])
+def test_ring_gemm_ignores_bad_tuning_knobs(gpu, orc, knob, value, monkeypatch):
+    """Environment variables cannot make the product wrong: the tile-group knobs are clamped to [1, tile rows] and the
+    timing ablations are not compiled into the library."""
+    monkeypatch.setenv(knob, value)
+    r, l, c = 300, 130, 260
+    rng = np.random.default_rng(11)
+    A, B = rnd(rng, r * l), rnd(rng, l * c)
+    want = orc.ring_gemm(A, B, r, l, c)
+    for mode in ("0", "2"):
+        monkeypatch.setenv("MPCX_GEMM_RNS", mode)
+        assert np.array_equal(gpu.ring_gemm(A, B, r, l, c), want), (knob, value, mode)
+
+
 def test_relayout(gpu):
     a = np.arange(37 * 91, dtype=np.int64)
     assert np.array_equal(gpu.relayout(a, 37, 91, 0, 1), np.ascontiguousarray(a.reshape(37, 91).T).ravel())

@@ -8,4 +8,4 @@ CMD="cd /tmp && export TMPDIR=/tmp && cd \$GRAFT_REPO_ROOT && rm -rf $D && mkdir
 timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $D/rd -o p -- python3 bench.py --steps 1 --warmup 0 --no-cpu --size 1024 > $D/rd.log 2>&1 && \
 timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $D/wr -o p -- python3 bench.py --steps 1 --warmup 0 --no-cpu --size 1024 > $D/wr.log 2>&1; echo exit=\$?"
 timeout 1700 /usr/local/graft/bin/gpurun --timeout 900 -- "$CMD" 2>&1 | tail -40
-python3 tools/pmc_bitwise_sum.py   # digest of the merged gpurun_out/pmc_bitwise -> profiles/r1_pmc_bitwise.json
+python3 tools/pmc_bitwise_sum.py   # digest of the merged gpurun_out/pmc_bitwise -> profiles/r2_pmc_bitwise.json

@@ -9,10 +9,16 @@ N = 1 << 24
 # algorithmic bytes per element and launch
 ALGO = {
     "pc_party_kernel": ("265 B protocol data + 64 B cached s bytes (+ 64 B of u for beta = 1, r = -1)", 329),
+    "pc_party_gen_kernel": ("265 B protocol data + 48 B of checkpoints (+ 64 B of u for beta = 1, r = -1)", 313),
     "pc_helper_kernel": ("2 x 128 B in + 1 B out", 257),
     "bit_share_kernel": ("8 B + 64 B random bytes in, 2 x 128 B out", 328),
+    "bit_share_gen_kernel": ("8 B + 48 B of checkpoints in, 2 x 128 B out", 312),
     "prg_mod67_kernel": ("64 bytes written per element and slice", 64),
+    "bi_sender_pre_kernel": ("8 (or 16) + 2 B in, 40 B out, 5 x 0.375 B/word of checkpoints", 54),
+    "bi_helper_pre_kernel": ("2 B in, 16 B out", 20),
+    "msb_last_kernel": ("2 B message + 2 B backup + bits in, 2 B out", 6.4),
 }
+MSB = ["msb_round_pre_kernel", "msb_round_mid_kernel", "msb_round_post_kernel"]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for kind, cname in (("rd", "FETCH_SIZE"), ("wr", "WRITE_SIZE")):
     for f in glob.glob(f"gpurun_out/pmc_bitwise/{kind}/*counter_collection.csv"):
@@ -20,7 +26,7 @@ for kind, cname in (("rd", "FETCH_SIZE"), ("wr", "WRITE_SIZE")):
             if r["Counter_Name"] != cname:
                 continue
             k = r["Kernel_Name"]
-            name = next((a for a in list(ALGO) + ["msb_round_pre_kernel", "msb_round_post_kernel"] if a in k), None)
+            name = next((a for a in sorted(ALGO, key=len, reverse=True) + MSB if a in k), None)
             if name is None:
                 continue
             if name.startswith("msb_round"):
@@ -43,8 +49,10 @@ for name, c in sorted(agg.items()):
     out[name] = e
 out["_note"] = ("separate --pmc passes of `bench.py --steps 1 --warmup 0 --no-cpu --size 1024` (2^24 elements); "
                 "FETCH_SIZE / WRITE_SIZE are KiB, FETCH_SIZE doubled (gfx950 tallies 128-B read requests at 64 B); msb rounds: "
-                "the first level moves 64 + 64 message bytes and 32 state bytes per element, every later level half of the one before")
-json.dump(out, open("profiles/r1_pmc_bitwise.json", "w"), indent=1)
+                "round_pre<first level> reads 32 B of G / P words and writes 64 B of message + 8 B of state + 2 B of backup per element; "
+                "round_mid<first level> reads the 64-byte message + 8 B of G1 + 8 B of state and writes the 32-byte message + "
+                "4 + 4 B of state, every later level half of the one before")
+json.dump(out, open("profiles/r2_pmc_bitwise.json", "w"), indent=1)
 for k, v in out.items():
     if k != "_note":
         print(k, {a: (round(b) if isinstance(b, float) else b) for a, b in v.items() if a != "algorithmic"})

@@ -8,8 +8,9 @@ import shutil
 import sys
 
 tag = sys.argv[1]
+ROUND = sys.argv[2] if len(sys.argv) > 2 else "r2"
 d = f"gpurun_out/prof_{tag}"
-shutil.copy(glob.glob(d + "/trace/*kernel_stats.csv")[0], "profiles/r1_bench_kernel_stats.csv")
+shutil.copy(glob.glob(d + "/trace/*kernel_stats.csv")[0], f"profiles/{ROUND}_bench_kernel_stats.csv")
 out = {}
 for p in ("pmc_rd", "pmc_wr", "pmc_sq"):
     for f in glob.glob(f"{d}/{p}/*counter_collection.csv"):
@@ -39,5 +40,7 @@ for gname in ("limb_gemm_kernel", "rns_gemm_kernel"):
         "mfma_int8_ops": g["SQ_INSTS_VALU_MFMA_MOPS_I8"]["avg_value"] * 512,
         "mfma_pipe_utilisation_at_held_clock": g["SQ_INSTS_VALU_MFMA_MOPS_I8"]["avg_value"] * 512 / (256 * 4 * 2048) / cyc,
     }
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in g:  # summed over the 1024 SIMDs
+        g["derived"]["mfma_busy_cycles_per_simd_cycle"] = g["SQ_VALU_MFMA_BUSY_CYCLES"]["avg_value"] / (1024 * cyc)
     print(gname, json.dumps(g["derived"], indent=1))
-json.dump(out, open("profiles/r1_pmc_summary.json", "w"), indent=1)
+json.dump(out, open(f"profiles/{ROUND}_pmc_summary.json", "w"), indent=1)
