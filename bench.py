@@ -57,6 +57,40 @@ def measured_traffic(n, world, kernel="limb_gemm_kernel"):
     return d["derived"]["hbm_read_bytes_per_launch"] + d["derived"]["hbm_write_bytes_per_launch"]
 
 
+class TableBuilder:
+    """PRG checkpoint tables are a serial host walk of a stream whose key is a compile-time constant: on a node with
+    several ranks one rank walks and the others load what it left in the library's on-disk cache (MPCX_CKPT_CACHE)."""
+
+    def __init__(self, ctx, dist, rank, world):
+        self.ctx, self.dist, self.rank, self.shared = ctx, dist, rank, dist is not None and world > 1
+        self.made_dir = None
+        if self.shared:
+            if "MPCX_CKPT_CACHE" not in os.environ:  # a directory of this job's own, removed when the job ends
+                self.made_dir = os.path.join(os.environ.get("TMPDIR", "/tmp"),
+                                             "mpcx_ckpt_%s" % os.environ.get("MASTER_PORT", "0"))
+                os.environ["MPCX_CKPT_CACHE"] = self.made_dir
+            os.makedirs(os.environ["MPCX_CKPT_CACHE"], exist_ok=True)
+
+    def cleanup(self):
+        if self.made_dir and self.rank == 0:
+            import shutil
+            shutil.rmtree(self.made_dir, ignore_errors=True)
+
+    def build(self, specs):
+        """specs: (seed, n_pops, n_buff) triples; the streams are walked on as many host threads."""
+        def walk():
+            th = [threading.Thread(target=self.ctx.call, args=("prg_ckpt_build", s, 0, p, b)) for s, p, b in specs]
+            [t.start() for t in th]
+            [t.join() for t in th]
+        if not self.shared:
+            return walk()
+        if self.rank == 0:
+            walk()
+        self.dist.barrier()
+        if self.rank != 0:
+            walk()  # finds the tables on disk
+
+
 def prof_read(ctx, name):
     ms, cnt = ctypes.c_double(), ctypes.c_uint64()
     ctx._call("mpcx_profile_read", name.encode(), ctypes.byref(ms), ctypes.byref(cnt))
@@ -64,8 +98,10 @@ def prof_read(ctx, name):
 
 
 class Aby3MatmulJob:
-    def __init__(self, ctx, torch, dev, n, rank, world, host_gather=False, rows=None, gather=None, gather_to="root"):
+    def __init__(self, ctx, torch, dev, n, rank, world, host_gather=False, rows=None, gather=None, gather_to="root",
+                 tables=None):
         self.ctx, self.torch, self.n, self.rank, self.world = ctx, torch, n, rank, world
+        tables = tables or TableBuilder(ctx, None, rank, 1)
         self.gather = world > 1 if gather is None else gather  # the collective also runs in a 1-rank process group
         self.host_gather = host_gather
         self.gather_to = gather_to  # "root": only rank 0 (the rank that faces the messenger) receives; "all": all-gather
@@ -76,6 +112,9 @@ class Aby3MatmulJob:
         self.plan = aby3_matmul_pop_plan(self.rows_total, self.l, self.c)
         i64 = torch.int64
         e = lambda k: torch.empty(k, dtype=i64, device=dev)
+        # pop-stream checkpoints for everything a step consumes (fresh engines every step) and for the inputs
+        pops = self.plan["total"]
+        tables.build([(k, pops, 0) for k in (KEY01, KEY12, KEY20)] + [(20, self.rows_total * self.l + self.l * self.c, 0)])
         # plaintext inputs: X then Y row-major from PRgenerator(20,0).pop_int64()
         self.X, self.Y = e(self.rows * self.l), e(self.l * self.c)
         ctx.call("prg_fill_pop", 20, 0, self.row0 * self.l, self.rows * self.l, self.X)
@@ -87,11 +126,6 @@ class Aby3MatmulJob:
                       if self.gather and (rank == 0 or gather_to == "all") else None)
         self.Zplain = [e(self.rows * self.c) for _ in range(3)]
         self.pending = [None, None, None]  # all-gathers in flight, per party
-        # pop-stream checkpoints for everything a step consumes (fresh engines every step)
-        pops = self.plan["total"]
-        for k in (KEY01, KEY12, KEY20):
-            ctx.call("prg_ckpt_build", k, 0, pops, 0)
-        ctx.call("prg_ckpt_build", 20, 0, self.rows_total * self.l + self.l * self.c, 0)
         ctx.sync()
 
     def step(self):
@@ -295,7 +329,16 @@ def _timed(torch, fn, reps=1):
     return (time.perf_counter() - t0) / reps, r
 
 
-def bitwise_rates(ctx, torch, dev, log2n=24, rank=0, world=1):
+def bitwise_table_specs(log2n, world):
+    """(seed, n_pops, n_buff) of every generator stream bitwise_rates reads: the SecureNN buffers of a 2^log2n-element
+    vector, its inputs from PRgenerator(22,0), and the pop streams of the ABY3 chain on world * 2^log2n elements (share:
+    one word per element and stream, bit_inject: up to six more)."""
+    nt = 1 << log2n
+    return ([(KEY01, 7 * nt * world, 128 * nt), (KEYS, 0, 67 * nt + 64), (22, 67 * nt, 0), (21, nt * world, 0)] +
+            [(k, 7 * nt * world, 0) for k in (KEY12, KEY20)])
+
+
+def bitwise_rates(ctx, torch, dev, log2n=24, rank=0, world=1, tables=None):
     """Secondary metrics, elements / s with every buffer resident in HBM (this rank's element range; merged over
     the ranks by merge_bitwise):
       * privateCompare, party role and helper role, as kernels (config 3's n = 2^24);
@@ -324,18 +367,15 @@ def bitwise_rates(ctx, torch, dev, log2n=24, rank=0, world=1):
 
     # ---- privateCompare kernels
     t0 = time.perf_counter()
-    # the two generators are walked on two host threads (each stream has its own lock)
-    walks = [threading.Thread(target=ctx.call, args=("prg_ckpt_build", KEY01, 0, 0, 128 * nt)),
-             threading.Thread(target=ctx.call, args=("prg_ckpt_build", KEYS, 0, 0, 67 * nt + 64))]
-    [t.start() for t in walks]
-    [t.join() for t in walks]
+    # the generators are walked on one host thread each (every stream has its own lock); with several ranks on the node
+    # one rank walks and the others load the tables it leaves on disk
+    # (main() has built them already when it shares them between ranks: no collective may run in here, where a rank
+    # that fails must still reach the gather of the results)
+    TableBuilder(ctx, None, rank, 1).build(bitwise_table_specs(log2n, world))
     out["ckpt_build_s"] = round(time.perf_counter() - t0, 2)
     # Inputs as test/test_securenn.cpp:160-175 draws them from PRgenerator(22,0), 67 pops per element: x, r (forced to
     # -1 when i % 5 == 2), beta = the low bit of a pop, then for every bit position k the share xs0[k] = (uint16)pop % 67
     # of party 0; party 1's share (bit_k(x) + 67 - xs0[k]) % 67 is what the party role of party 1 would be handed.
-    t0 = time.perf_counter()
-    ctx.call("prg_ckpt_build", 22, 0, 67 * nt, 0)
-    out["input_ckpt_build_s"] = round(time.perf_counter() - t0, 2)
     xb = torch.empty(64 * n, dtype=torch.int16, device=dev)
     xb1 = torch.empty(64 * n, dtype=torch.int16, device=dev)
     beta = torch.empty(n, dtype=torch.int8, device=dev)
@@ -551,8 +591,9 @@ def main():
     ctx = Context(dev_index)
     ctx.call("set_stream", torch.cuda.current_stream().cuda_stream)
 
+    tables = TableBuilder(ctx, dist, rank, world)
     job = Aby3MatmulJob(ctx, torch, dev, args.size, rank, world, host_gather=args.dist_backend == "gloo", rows=args.rows or None,
-                        gather=dist is not None, gather_to=args.gather)
+                        gather=dist is not None, gather_to=args.gather, tables=tables)
 
     def barrier():
         if dist is not None:
@@ -584,8 +625,10 @@ def main():
     if not args.no_bitwise:
         job = job.shape_only()  # frees the matmul operands before the element-wise runs allocate theirs
         torch.cuda.empty_cache()
+        if tables.shared:
+            tables.build(bitwise_table_specs(args.bitwise_log2n, world))
         try:
-            mine = bitwise_rates(ctx, torch, dev, args.bitwise_log2n, rank, world)
+            mine = bitwise_rates(ctx, torch, dev, args.bitwise_log2n, rank, world, tables)
         except Exception as ex:  # secondary metric must not hide the headline number
             mine = {"error": f"rank {rank}: {ex}"}
         bitwise = [mine]
@@ -642,6 +685,7 @@ def main():
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()
+        tables.cleanup()
         dist.destroy_process_group()
 
 

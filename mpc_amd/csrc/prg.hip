@@ -309,6 +309,7 @@ int mpcx_prg_table(mpcx_ctx *ctx, u64 seed, u64 lcg, u64 t_end, const PrgCk **de
         ckpt_load(T, seed, lcg);
     }
     const u64 need = t_end / PRG_CK + 1; // checkpoints 0 .. floor(t_end/PRG_CK)
+    if (T.host.size() < need) ckpt_load(T, seed, lcg); // another process of the node may have walked further already
     if (T.host.size() < need) {
         // walk a little past the request (between 4 Ki and 64 Ki checkpoints) so that the device copy grows once in
         // many calls

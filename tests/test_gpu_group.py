@@ -102,3 +102,30 @@ def test_host_benchmark_over_a_group_verifies():
     r = subprocess.run([exe, "--engine", "aby3", "--width", "512", "--vec", "100000", "--repeat", "1", "--no-mlp"],
                        capture_output=True, text=True, timeout=600, env=dict(os.environ, MPCX_DEVICES="0,0"))
     assert r.returncode == 0 and "all results verified" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+def test_checkpoint_tables_are_shared_through_the_disk_cache(tmp_path):
+    """MPCX_CKPT_CACHE: a process leaves the checkpoint table of a stream it walked in the directory; the next process
+    loads it (and produces the same words); a truncated or foreign file is ignored."""
+    import sys
+    prog = ("import sys, numpy as np; sys.path.insert(0, %r); from mpc_amd import Context; c = Context(0); "
+            "d = c.empty(np.int64, 1000); c.call('prg_fill_pop', 0x77, 0, 3_000_000, 1000, d); c.sync(); "
+            "print('WORDS', ' '.join('%%x' %% (int(v) & (2**64 - 1)) for v in d.to_host()[:8]))" % ROOT)
+    env = dict(os.environ, MPCX_CKPT_CACHE=str(tmp_path), MPCX_PRG_WALK_AHEAD="0")
+    run = lambda e: subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=300, env=e)
+    first = run(env)
+    assert first.returncode == 0, first.stderr[-2000:]
+    files = list(tmp_path.glob("prg_*.ckpt"))
+    assert len(files) == 1 and files[0].stat().st_size > 24 * (3_000_000 // 64)
+    second = run(env)
+    assert second.returncode == 0 and second.stdout == first.stdout and "WORDS" in first.stdout
+    no_cache = run(dict(os.environ, MPCX_CKPT_CACHE=""))
+    assert no_cache.stdout == first.stdout
+    data = files[0].read_bytes()
+    files[0].write_bytes(data[: len(data) // 2])  # truncated: ignored, walked again and replaced
+    third = run(env)
+    assert third.returncode == 0 and third.stdout == first.stdout
+    assert files[0].stat().st_size == len(data)
+    files[0].write_bytes(data[:32] + bytes(len(data) - 32))  # right header, wrong states: rejected by the first entry
+    fourth = run(env)
+    assert fourth.returncode == 0 and fourth.stdout == first.stdout
