@@ -646,7 +646,10 @@ def main():
         import mpc_amd
         nprod = mpc_amd.load_library().mpcx_ring_gemm_products(ctypes.c_uint64(job.rows), ctypes.c_uint64(job.l),
                                                                ctypes.c_uint64(job.c))
-        kernel = "rns_gemm_kernel" if nprod == 18 else "limb_gemm_kernel"
+        lib = mpc_amd.load_library()
+        lib.mpcx_ring_gemm_kernel_name.restype = ctypes.c_char_p
+        kernel = lib.mpcx_ring_gemm_kernel_name(ctypes.c_uint64(job.rows), ctypes.c_uint64(job.l),
+                                                ctypes.c_uint64(job.c)).decode()
         avg_s = gemm_ms / gemm_cnt * 1e-3
         achieved = ops_per_product * 3 * args.steps / (gemm_ms * 1e-3) / 1e12
         issued = achieved * nprod / 36

@@ -93,6 +93,10 @@ int mpcx_ring_gemm_u64(mpcx_ctx *ctx, const int64_t *A, const int64_t *B, int64_
  * positional form) or 18 (residues modulo 18 coprime moduli + CRT), chosen by size; MPCX_GEMM_RNS=0 / 2 in the
  * environment forces the first / the second.  No counterpart in the reference (Eigen's operator*). */
 int mpcx_ring_gemm_products(uint64_t r, uint64_t l, uint64_t c);
+/* Name of the GEMM kernel such a product runs in ("limb_gemm_kernel", "rns_gemm_kernel": 256 x 256 block tiles,
+ * "rns_gemm_wide_kernel": 384 x 256, the default of the residue form; MPCX_RNS_TILE=0 selects the former) -- for
+ * profilers that match kernel names.  The string is static.  No counterpart in the reference. */
+const char *mpcx_ring_gemm_kernel_name(uint64_t r, uint64_t l, uint64_t c);
 /* mpcx_ring_gemm_u64 for callers that cannot allocate device memory (code under HIP graph capture, tight serving
  * loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments and results; the limb
  * planes live in a file-scope device array of mpcx_ring_gemm_noalloc_limit() = 16 MiB per GPU (held until the process

@@ -557,6 +557,10 @@ int mpcx_ring_gemm_u64(mpcx_ctx *ctx, const int64_t *A, const int64_t *B, int64_
 }
 
 int mpcx_ring_gemm_products(uint64_t r, uint64_t l, uint64_t c) { return ring_gemm_use_rns(r, l, c) ? 18 : 36; }
+const char *mpcx_ring_gemm_kernel_name(uint64_t r, uint64_t l, uint64_t c) {
+    if (!ring_gemm_use_rns(r, l, c)) return "limb_gemm_kernel";
+    return ring_gemm_rns_wide() ? "rns_gemm_wide_kernel" : "rns_gemm_kernel";
+}
 
 int mpcx_relayout(mpcx_ctx *ctx, const int64_t *src, int64_t *dst, uint64_t rows, uint64_t cols, int lay_src,
                   int lay_dst) {

@@ -13,6 +13,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <mutex>
+#include <type_traits>
 
 #include "mpcx_internal.h"
 
@@ -133,27 +134,56 @@ __global__ __launch_bounds__(256) void rns_split_kernel(SplitJobs jobs, u64 K, u
     if (kg >= Kp) return; // the last 64-wide block of the padded K range may stick out (Kp is a multiple of 32)
     i8 *dst = J.planes + ((kg >> 5) * J.Op + o0 + oo) * RK + (kg & 31);
     const u64 plane_stride = J.Op * Kp;
-    // residue: t = sum d_j (256^j mod m) (|t| <= 8 * 128 * 128), minus m times the nearest integer to t / m taken in
-    // float: the quotient is off by one only within 1e-4 of a tie, so |r| <= m/2 + 0.03, a signed byte (for m = 256
-    // the two ties +-128 are the same residue).
+    // residue: t = sum d_j (256^j mod m) (|t| <= 8 * 128 * 128) minus m times the nearest integer to t / m, all in
+    // float, where these integers are exact.  For the odd moduli t / m is at least 1 / 510 away from a tie, forty times
+    // the error of the float product, so |r| <= (m - 1) / 2 <= 127; for m = 256, t is the lowest digit itself and
+    // r = t.  The dot product starts at 128, so that r + 128 is a byte that v_cvt_pk_u8_f32 converts and places in
+    // one instruction; flipping the top bits of the four bytes takes the bias off again.
+    // Written stage by stage over the lane's 16 words so that no instruction waits for the one before it; the dot
+    // products are spelled out because the three-address form (accumulator from another register: no copy of the
+    // bias per product) is not what the compiler picks for the builtin.
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    i32 bias = 128;
+    asm volatile("" : "+v"(bias));
 #pragma unroll 1
     for (int i = 0; i < NP; i++) {
-        const i32 m = (i32)T.m[i], clo = T.clo[i], chi = T.chi[i];
-        const float w = T.w[i];
-        u32 wd[4];
+        const i32 clo = T.clo[i], chi = T.chi[i];
+        const float w = T.w[i], mf = (float)T.m[i], wb = -128.f * w;
+        const v2f w2 = {w, w}, wb2 = {wb, wb}, nm2 = {-mf, -mf};
+        i32 t[16];
 #pragma unroll
-        for (u32 d = 0; d < 4; d++) {
-            u32 r[4];
+        for (u32 q = 0; q < 16; q++)
+            asm("v_dot4_i32_i8 %0, %1, %2, %3" : "=v"(t[q]) : "v"((u32)y[q]), "s"(clo), "v"(bias));
 #pragma unroll
-            for (u32 e = 0; e < 4; e++) {
-                const u64 yy = y[4 * d + e];
-                const i32 t = __builtin_amdgcn_sdot4((i32)(u32)(yy >> 32), chi,
-                                                     __builtin_amdgcn_sdot4((i32)(u32)yy, clo, 0, false), false);
-                r[e] = (u32)(t - (i32)rintf((float)t * w) * m);
-            }
-            // the low bytes of the four residues, two byte permutes and an or
-            wd[d] = __builtin_amdgcn_perm(r[1], r[0], 0x0c0c0400u) | __builtin_amdgcn_perm(r[3], r[2], 0x04000c0cu);
+        for (u32 q = 0; q < 16; q++)
+            asm("v_dot4_i32_i8 %0, %1, %2, %3" : "=v"(t[q]) : "v"((u32)(y[q] >> 32)), "s"(chi), "v"(t[q]));
+        // a dot product's result may be read by another kind of instruction three issue slots later at the
+        // earliest; the compiler cannot see what the asm statements are, so the distance is made here
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_nop 2");
+        __builtin_amdgcn_sched_barrier(0);
+        v2f tf[8], qf[8];
+#pragma unroll
+        for (u32 q = 0; q < 8; q++) {
+            tf[q][0] = (float)t[2 * q];
+            tf[q][1] = (float)t[2 * q + 1];
         }
+#pragma unroll
+        for (u32 q = 0; q < 8; q++) qf[q] = __builtin_elementwise_fma(tf[q], w2, wb2);
+#pragma unroll
+        for (u32 q = 0; q < 8; q++) {
+            qf[q][0] = rintf(qf[q][0]);
+            qf[q][1] = rintf(qf[q][1]);
+        }
+#pragma unroll
+        for (u32 q = 0; q < 8; q++) tf[q] = __builtin_elementwise_fma(qf[q], nm2, tf[q]);
+        u32 wd[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (u32 e = 0; e < 4; e++)
+#pragma unroll
+            for (u32 d = 0; d < 4; d++) wd[d] = __builtin_amdgcn_cvt_pk_u8_f32(tf[2 * d + (e >> 1)][e & 1], e, wd[d]);
+#pragma unroll
+        for (u32 d = 0; d < 4; d++) wd[d] ^= 0x80808080u;
         st_stream((uint4 *)(dst + (u64)i * plane_stride), wd[0], wd[1], wd[2], wd[3]);
     }
 }
@@ -317,6 +347,231 @@ __global__ __launch_bounds__(512) void rns_gemm_kernel(const i8 *__restrict__ Ap
         }
 }
 
+// The same product on a 384 x 256 block tile: eight waves as 2(M) x 4(N), a wave owns the even or the odd 32-row tiles
+// of the block tile x 64 columns = 6 x 2 MFMA tiles (12 accumulators, 192 registers), so a K block stages 20 KiB for
+// 96 MFMAs instead of 16 KiB for 64 -- a sixth fewer bytes through LDS-DMA per MFMA, which is what bounds the loop.
+// One fragment set only: the A fragment of a row tile is read again for the next K block right after its two MFMAs
+// were issued, the two B fragments alternate between two register pairs.  A stage is two K blocks = 40 KiB (five
+// 1-KiB pieces per wave), three buffers; the barrier of a stage sits in the middle of its second K block, where the
+// reads issued before it have had six MFMAs to return and six more cover the first reads from the next buffer.
+//
+// Rows are padded to 128 only: the last tile row of a product may hold 128 or 256 rows (NPW = 3 or 4 pieces per wave
+// and stage instead of 5, NMI = 2 or 4 row tiles per wave instead of 6), so that no MFMA and no staged byte is spent
+// on padding beyond 127 rows.
+constexpr u32 TMW = 384, SKW = 2, MGRAN = 128;
+constexpr u32 KBW_BYTES = (TMW + TN) * RK;    // 20 KiB
+constexpr u32 STAGEW_BYTES = SKW * KBW_BYTES; // 40 KiB
+
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm" // m0 on a clobber list: nothing else in the kernel uses it
+template <u32 NPW>
+__device__ __forceinline__ void rns_wide_tile(i8 *lds, const i8 *__restrict__ Ai, const i8 *__restrict__ Bi,
+                                              u8 *__restrict__ Yi, u32 Mp, u32 Np, u32 nkb, u32 tm, u32 tn, u32 m,
+                                              u32 inv, u32 off, u64 magic) {
+    constexpr u32 NMI = 2 * NPW - 4;     // row tiles per wave: 6, 4, 2
+    constexpr u32 VT = 2 * NMI;          // 32-row tiles of A in this block tile
+    constexpr u32 PKB = VT + TN / 32;    // pieces per K block
+    const u32 tid = threadIdx.x, lane = tid & 63;
+    const u32 wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const u32 wm = wid >> 2, wn = wid & 3, lr = lane & 31, lh = lane >> 5;
+
+    // staging plan: NPW pieces of 1 KiB per wave and stage: piece p -> K block p / PKB, then A rows 32 (p % PKB) ..
+    // (p % PKB < VT) or B rows 32 (p % PKB - VT) ..
+    const u32 lrow = lane >> 1;
+    const u32 lsrc = lrow * RK + (((lane & 1) ^ ((lrow >> 3) & 1)) << 4);
+    const i8 *gsrc[NPW];
+    u32 gstep[NPW], ldst[NPW];
+#pragma unroll
+    for (u32 q = 0; q < NPW; q++) {
+        const u32 p = wid * NPW + q, kb = p / PKB, idx = p % PKB;
+        if (idx < VT) {
+            gsrc[q] = Ai + ((u64)kb * Mp + (u64)tm * TMW + idx * 32) * RK;
+            gstep[q] = SKW * Mp * RK;
+            ldst[q] = kb * KBW_BYTES + idx * 1024;
+        } else {
+            gsrc[q] = Bi + ((u64)kb * Np + (u64)tn * TN + (idx - VT) * 32) * RK;
+            gstep[q] = SKW * Np * RK;
+            ldst[q] = kb * KBW_BYTES + TMW * RK + (idx - VT) * 1024;
+        }
+    }
+    // The DMA is issued from inline assembly (SGPR base + per-lane offset): with the builtin the compiler takes every
+    // later LDS wait to zero outstanding reads instead of counting them, which stalls the in-place fragment reloads.
+    const u32 lds0 = (u32)(size_t)(__attribute__((address_space(3))) void *)lds;
+    auto stage_piece = [&](u32 buf, u32 q) {
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                     :
+                     : "v"(lsrc), "s"(gsrc[q]), "s"(lds0 + buf * STAGEW_BYTES + ldst[q])
+                     : "memory", "m0");
+        gsrc[q] += gstep[q];
+    };
+    const u32 fsw = (lh ^ ((lr >> 3) & 1)) << 4;
+    const u32 a_off = (wm * 32 + lr) * RK + fsw; // row tile 2 mi + wm
+    const u32 b_off = TMW * RK + (wn * 64 + lr) * RK + fsw;
+
+    v16i acc[NMI][2];
+#pragma unroll
+    for (u32 a = 0; a < NMI; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[a][b][r] = 0;
+
+    const u32 nst = nkb / SKW;
+#pragma unroll
+    for (u32 q = 0; q < NPW; q++) stage_piece(0, q);
+    if (nst > 1) {
+#pragma unroll
+        for (u32 q = 0; q < NPW; q++) stage_piece(1, q);
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NPW) : "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+#define MPCX_PIN() __builtin_amdgcn_sched_barrier(0)
+    auto rdA = [&](u32 buf, u32 s, u32 mi) {
+        return *(const v4i *)(lds + buf * STAGEW_BYTES + s * KBW_BYTES + a_off + mi * 64 * RK);
+    };
+    auto rdB = [&](u32 buf, u32 s, u32 ni) {
+        return *(const v4i *)(lds + buf * STAGEW_BYTES + s * KBW_BYTES + b_off + ni * 32 * RK);
+    };
+    constexpr u32 H = NMI / 2; // row tiles of the second K block multiplied before the barrier
+    v4i a[NMI], b[2], bn[2];
+    // head: what follows a stage's barrier -- the first fragments of stage `cur` (landed: the barrier said so) are read
+    // and, unless this is the very first stage, the second half of the previous stage's second K block is multiplied,
+    // each A fragment replaced right after its two MFMAs.  tail: the same MFMAs with nothing left to read.
+    auto head = [&](u32 cur, auto first_c) {
+        constexpr bool FIRST = decltype(first_c)::value;
+        b[0] = rdB(cur, 0, 0);
+        b[1] = rdB(cur, 0, 1);
+#pragma unroll
+        for (u32 mi = 0; mi < H; mi++) a[mi] = rdA(cur, 0, mi);
+        MPCX_PIN();
+#pragma unroll
+        for (u32 mi = H; mi < NMI; mi++) {
+            if (!FIRST) {
+                acc[mi][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[mi], bn[0], acc[mi][0], 0, 0, 0);
+                acc[mi][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[mi], bn[1], acc[mi][1], 0, 0, 0);
+            }
+            MPCX_PIN();
+            a[mi] = rdA(cur, 0, mi);
+            MPCX_PIN();
+        }
+    };
+    auto tail = [&]() {
+#pragma unroll
+        for (u32 mi = H; mi < NMI; mi++) {
+            acc[mi][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[mi], bn[0], acc[mi][0], 0, 0, 0);
+            acc[mi][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[mi], bn[1], acc[mi][1], 0, 0, 0);
+        }
+    };
+    // body: the first K block of stage `cur`, the first half of its second K block and the stage's barrier; with MORE
+    // the pieces of the stage after the next are issued in between (one after every second MFMA pair), into the buffer
+    // of the previous stage, free since that stage's barrier
+    auto body = [&](u32 cur, auto more_c) {
+        constexpr bool MORE = decltype(more_c)::value;
+        const u32 fill = cur == 0 ? 2 : cur - 1;
+        u32 q = 0;
+        bn[0] = rdB(cur, 1, 0);
+        bn[1] = rdB(cur, 1, 1);
+#pragma unroll
+        for (u32 mi = 0; mi < NMI; mi++) {
+            acc[mi][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[mi], b[0], acc[mi][0], 0, 0, 0);
+            acc[mi][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[mi], b[1], acc[mi][1], 0, 0, 0);
+            MPCX_PIN();
+            a[mi] = rdA(cur, 1, mi);
+            if (MORE && (mi & 1) == 0 && q < NPW) stage_piece(fill, q++);
+            MPCX_PIN();
+        }
+#pragma unroll
+        for (u32 mi = 0; mi < H; mi++) {
+            acc[mi][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[mi], bn[0], acc[mi][0], 0, 0, 0);
+            acc[mi][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[mi], bn[1], acc[mi][1], 0, 0, 0);
+            MPCX_PIN();
+            if (MORE && (mi != 1 || NMI < 6) && q < NPW) stage_piece(fill, q++);
+            MPCX_PIN();
+        }
+        if (MORE) {
+#pragma unroll
+            for (; q < NPW; q++) stage_piece(fill, q);
+            // the next stage's pieces are older than the NPW just issued
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NPW) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+    };
+    u32 cur = 0, t = 0;
+    head(0, std::true_type{});
+    if (nst >= 3) {
+        body(0, std::true_type{});
+        cur = 1;
+        for (t = 1; t + 2 < nst; t++) {
+            head(cur, std::false_type{});
+            body(cur, std::true_type{});
+            cur = cur == 2 ? 0 : cur + 1;
+        }
+    }
+#pragma unroll 1
+    for (; t < nst; t++) { // the last two stages: nothing left to issue
+        if (t > 0) head(cur, std::false_type{});
+        body(cur, std::false_type{});
+        cur = cur == 2 ? 0 : cur + 1;
+    }
+    tail();
+#undef MPCX_PIN
+
+    // epilogue: acc mod m, times inv, mod m -> one byte
+#pragma unroll
+    for (u32 mi = 0; mi < NMI; mi++)
+#pragma unroll
+        for (u32 ni = 0; ni < 2; ni++) {
+            const u32 col = tn * TN + wn * 64 + ni * 32 + lr;
+            const u32 row0 = tm * TMW + (2 * mi + wm) * 32 + 4 * lh;
+#pragma unroll
+            for (u32 r = 0; r < 16; r++) {
+                const u32 row = row0 + (r & 3) + 8 * (r >> 2);
+                u32 x = (u32)(acc[mi][ni][r] + (i32)off); // |acc| < 2^28 <= off
+                x -= (u32)(((u64)x * magic) >> 40) * m;
+                u32 yv = x * inv;
+                yv -= (u32)(((u64)yv * magic) >> 40) * m;
+                Yi[(u64)row * Np + col] = (u8)yv;
+            }
+        }
+}
+
+#pragma clang diagnostic pop
+
+// grid (tiles_m * tiles_n * NP); Mp is a multiple of 128, tiles_m = ceil(Mp / 384)
+__global__ __launch_bounds__(512) void rns_gemm_wide_kernel(const i8 *__restrict__ Apl, const i8 *__restrict__ Bpl,
+                                                            u8 *__restrict__ Y, u32 Mp, u32 Np, u32 nkb, u32 tiles_m,
+                                                            u32 tiles_n, u32 GM, RnsTab T) {
+    __shared__ __attribute__((aligned(1024))) i8 lds[3 * STAGEW_BYTES];
+    // XCD-aware order over the whole launch: workgroups b, b+8, .. share an L2; every XCD takes one contiguous run of
+    // the list (modulus, tile) -- about NP / 8 moduli -- so that the 32 tiles it works on at a time are one 4-row
+    // group of one modulus' planes
+    const u32 nwg = tiles_m * tiles_n, total = nwg * NP;
+    const u32 bid = blockIdx.x;
+    const u32 qq = total / 8, rem = total % 8, xcd = bid % 8;
+    const u32 pos = (xcd < rem ? xcd * (qq + 1) : rem * (qq + 1) + (xcd - rem) * qq) + bid / 8;
+    const u32 mod_i = pos / nwg, swz = pos % nwg;
+    const u32 per_group = GM * tiles_n;
+    const u32 group = swz / per_group, in_group = swz % per_group;
+    const u32 first_m = group * GM;
+    const u32 gsz = (tiles_m - first_m < GM) ? tiles_m - first_m : GM;
+    const u32 tm = first_m + in_group % gsz, tn = in_group / gsz;
+
+    const i8 *Ai = Apl + (u64)mod_i * nkb * Mp * RK;
+    const i8 *Bi = Bpl + (u64)mod_i * nkb * Np * RK;
+    u8 *Yi = Y + (u64)mod_i * Mp * Np;
+    const u32 m = T.m[mod_i], inv = T.inv[mod_i], off = T.off_acc[mod_i];
+    const u64 magic = T.magic40[mod_i];
+    const u32 rows = Mp - tm * TMW; // rows of this block tile that exist
+    if (rows >= TMW)
+        rns_wide_tile<5>(lds, Ai, Bi, Yi, Mp, Np, nkb, tm, tn, m, inv, off, magic);
+    else if (rows == 2 * MGRAN)
+        rns_wide_tile<4>(lds, Ai, Bi, Yi, Mp, Np, nkb, tm, tn, m, inv, off, magic);
+    else
+        rns_wide_tile<3>(lds, Ai, Bi, Yi, Mp, Np, nkb, tm, tn, m, inv, off, magic);
+}
+
 // Z[m][n] (+)= (sum_i y_i cM_i - round(sum_i y_i / m_i) Mmod) + add - sub, four columns per lane
 __global__ __launch_bounds__(256) void rns_combine_kernel(const u8 *__restrict__ Y, u64 Mp, u64 Np, u64 M, u64 N,
                                                           const u64 *__restrict__ add, const u64 *__restrict__ sub,
@@ -378,10 +633,32 @@ bool ring_gemm_use_rns(u64 r, u64 l, u64 c) {
     return r * c >= 2560ull * 2560ull && l >= 2048;
 }
 
+// MPCX_RNS_TILE: 0 = 256 x 256 block tiles, otherwise (default) 384 x 256; read on every call
+bool ring_gemm_rns_wide() {
+    const char *e = getenv("MPCX_RNS_TILE");
+    return e ? atoi(e) != 0 : true;
+}
+
+namespace {
+struct RnsGeom {
+    bool wide;
+    u64 Mp, Np, lc, Kp;
+};
+RnsGeom rns_geom(int nparts, u64 r, u64 l, u64 c) {
+    RnsGeom g;
+    g.wide = ring_gemm_rns_wide();
+    g.Mp = round_up(r, g.wide ? MGRAN : TM);
+    g.Np = round_up(c, TN);
+    g.lc = rns_part_chunk_len(nparts, l);
+    g.Kp = round_up((u64)nparts * g.lc, g.wide ? SKW * RK : KSTAGE);
+    return g;
+}
+} // namespace
+
 u64 ring_gemm_rns_ws_bytes(int nparts, u64 r, u64 l, u64 c) {
-    const u64 Mp = round_up(r, TM), Np = round_up(c, TN);
-    const u64 Kp = round_up((u64)nparts * rns_part_chunk_len(nparts, l), KSTAGE);
-    const u64 a = (NP * Mp * Kp + 255) & ~255ull, b = (NP * Np * Kp + 255) & ~255ull, y = (NP * Mp * Np + 255) & ~255ull;
+    const RnsGeom g = rns_geom(nparts, r, l, c);
+    const u64 a = (NP * g.Mp * g.Kp + 255) & ~255ull, b = (NP * g.Np * g.Kp + 255) & ~255ull,
+              y = (NP * g.Mp * g.Np + 255) & ~255ull;
     return a + b + y;
 }
 
@@ -392,9 +669,8 @@ int ring_gemm_parts_rns(mpcx_ctx *ctx, const GemmPart *parts, int nparts, u64 r,
     MPCX_REQUIRE(r < (1u << 30) && c < (1u << 30) && l < (1u << 30), "ring gemm: dimension too large");
     MPCX_REQUIRE(nparts >= 1 && nparts <= 8, "ring gemm: bad part count");
     const RnsTab &T = rns_tab();
-    const u64 Mp = round_up(r, TM), Np = round_up(c, TN);
-    const u64 lc = rns_part_chunk_len(nparts, l);
-    const u64 Kp = round_up((u64)nparts * lc, KSTAGE);
+    const RnsGeom geom = rns_geom(nparts, r, l, c);
+    const u64 Mp = geom.Mp, Np = geom.Np, lc = geom.lc, Kp = geom.Kp;
     MPCX_REQUIRE((u64)nparts * lc <= 8192, "ring gemm: cannot chunk K");
     // the split grid has one y block per 64 rows, and the kernels step through the planes with 32-bit byte offsets
     MPCX_REQUIRE(Mp / 64 <= 65535 && Np / 64 <= 65535, "ring gemm: more than 4194240 rows or columns");
@@ -403,7 +679,7 @@ int ring_gemm_parts_rns(mpcx_ctx *ctx, const GemmPart *parts, int nparts, u64 r,
     i8 *Apl = (i8 *)ws;
     i8 *Bpl = Apl + ((NP * Mp * Kp + 255) & ~255ull);
     u8 *Y = (u8 *)Bpl + ((NP * Np * Kp + 255) & ~255ull);
-    const u32 tiles_m = (u32)(Mp / TM), tiles_n = (u32)(Np / TN);
+    const u32 tiles_m = (u32)(geom.wide ? ceil_div(Mp, TMW) : Mp / TM), tiles_n = (u32)(Np / TN);
     const u32 nkb = (u32)(Kp / RK);
     const u64 soA = layA ? 1 : l, skA = layA ? r : 1;
     const u64 soB = layB ? l : 1, skB = layB ? 1 : c;
@@ -443,8 +719,12 @@ int ring_gemm_parts_rns(mpcx_ctx *ctx, const GemmPart *parts, int nparts, u64 r,
         }
         {
             ProfScope ps(ctx, PROF_GEMM);
-            hipLaunchKernelGGL(rns_gemm_kernel, dim3(tiles_m * tiles_n, NP), dim3(512), 0, ctx->stream, Apl, Bpl, Y, (u32)Mp,
-                               (u32)Np, nkb, tiles_m, tiles_n, gm, T);
+            if (geom.wide)
+                hipLaunchKernelGGL(rns_gemm_wide_kernel, dim3(tiles_m * tiles_n * NP), dim3(512), 0, ctx->stream, Apl, Bpl, Y,
+                                   (u32)Mp, (u32)Np, nkb, tiles_m, tiles_n, gm, T);
+            else
+                hipLaunchKernelGGL(rns_gemm_kernel, dim3(tiles_m * tiles_n, NP), dim3(512), 0, ctx->stream, Apl, Bpl, Y,
+                                   (u32)Mp, (u32)Np, nkb, tiles_m, tiles_n, gm, T);
         }
         {
             ProfScope ps(ctx, PROF_SPLIT);

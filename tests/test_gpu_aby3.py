@@ -117,6 +117,19 @@ def test_ring_gemm_both_formulations(gpu, orc, mode, monkeypatch):
         assert np.array_equal(gpu.ring_gemm(A, B, r, l, c), orc.ring_gemm(A, B, r, l, c))
 
 
+@pytest.mark.parametrize("tile", ["0", "1"])
+def test_rns_gemm_block_tile_shapes(gpu, orc, tile, monkeypatch):
+    """The residue kernel's two block tiles (256 x 256; 384 x 256 with a last tile row of 128, 256 or 384 rows), forced
+    for small products whose row counts hit every case, K from one stage to several, against the oracle word for word."""
+    monkeypatch.setenv("MPCX_GEMM_RNS", "2")
+    monkeypatch.setenv("MPCX_RNS_TILE", tile)
+    rng = np.random.default_rng(5)
+    for r, l, c in ((100, 40, 70), (200, 64, 256), (384, 65, 300), (500, 130, 257), (650, 200, 64), (800, 333, 520),
+                    (1153, 96, 129)):
+        A, B = rnd(rng, r * l), rnd(rng, l * c)
+        assert np.array_equal(gpu.ring_gemm(A, B, r, l, c), orc.ring_gemm(A, B, r, l, c)), (tile, r, l, c)
+
+
 @pytest.mark.parametrize("knob,value", [("MPCX_GEMM_GM", "0"), ("MPCX_GEMM_GM", "-3"), ("MPCX_GEMM_GM", "1000000"),
                                         ("MPCX_RNS_GM", "0"), ("MPCX_RNS_GM", "99"), ("MPCX_GEMM_ABLATE", "1"),
                                         ("MPCX_GEMM_ABLATE", "3")])

@@ -9,6 +9,7 @@ g = torch.Generator(device=dev); g.manual_seed(1)
 def rnd(n): return torch.randint(-2**63, 2**63 - 1, (n,), dtype=torch.int64, device=dev, generator=g)
 cases = {"random": (rnd(r * l), rnd(l * c)), "zeros": (torch.zeros(r * l, dtype=torch.int64, device=dev), torch.zeros(l * c, dtype=torch.int64, device=dev)),
          "small (|x| < 2^7: one nonzero digit)": (torch.randint(-100, 100, (r * l,), dtype=torch.int64, device=dev, generator=g), torch.randint(-100, 100, (l * c,), dtype=torch.int64, device=dev, generator=g))}
+cases["A zeros, B random"] = (cases["zeros"][0], cases["random"][1])
 Z = torch.empty(r * c, dtype=torch.int64, device=dev)
 for name, (A, B) in cases.items():
     for _ in range(3): ctx.call("ring_gemm_u64", A, B, Z, r, l, c, 0, 0, 0, 0)

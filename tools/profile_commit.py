@@ -18,7 +18,7 @@ for p in ("pmc_rd", "pmc_wr", "pmc_sq"):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"]
             name = ("limb_gemm_kernel" if "limb_gemm" in k else "split_limbs_kernel" if "split_limbs" in k
-                    else "rns_gemm_kernel" if "rns_gemm" in k else "rns_split_kernel" if "rns_split" in k
+                    else "rns_gemm_wide_kernel" if "rns_gemm_wide" in k else "rns_gemm_kernel" if "rns_gemm" in k else "rns_split_kernel" if "rns_split" in k
                     else "rns_combine_kernel" if "rns_combine" in k else None)
             if name:
                 dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
@@ -26,7 +26,7 @@ for p in ("pmc_rd", "pmc_wr", "pmc_sq"):
         for (name, cn), v in agg.items():
             out.setdefault(name, {})[cn] = {"launches": len(v), "avg_value": sum(x for x, _ in v) / len(v),
                                             "avg_duration_us": sum(t for _, t in v) / len(v)}
-for gname in ("limb_gemm_kernel", "rns_gemm_kernel"):
+for gname in ("limb_gemm_kernel", "rns_gemm_kernel", "rns_gemm_wide_kernel"):
     if gname not in out:
         continue
     g = out[gname]
