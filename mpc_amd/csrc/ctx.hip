@@ -6,6 +6,7 @@
 #include <condition_variable>
 #include <deque>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <thread>
 
@@ -100,23 +101,25 @@ void mpcx_parallel_memcpy(void *dst, const void *src, u64 bytes) {
         std::mutex mu;
         std::condition_variable cv;
         u64 left;
-    } latch;
-    latch.left = pieces - 1;
+    };
+    // shared with the jobs: the last one may still be inside its unlock when this function returns
+    auto latch = std::make_shared<Latch>();
+    latch->left = pieces - 1;
     {
         std::lock_guard<std::mutex> lk(P.mu);
         for (u64 k = 1; k < pieces; k++) {
             const u64 off = k * per, len = off >= bytes ? 0 : (bytes - off < per ? bytes - off : per);
-            P.jobs.emplace_back([=, &latch] {
+            P.jobs.emplace_back([=] {
                 if (len) memcpy((char *)dst + off, (const char *)src + off, len);
-                std::lock_guard<std::mutex> g(latch.mu);
-                if (--latch.left == 0) latch.cv.notify_one();
+                std::lock_guard<std::mutex> g(latch->mu);
+                if (--latch->left == 0) latch->cv.notify_one();
             });
         }
     }
     P.cv.notify_all();
     memcpy(dst, src, per < bytes ? per : bytes);
-    std::unique_lock<std::mutex> lk(latch.mu);
-    latch.cv.wait(lk, [&] { return latch.left == 0; });
+    std::unique_lock<std::mutex> lk(latch->mu);
+    latch->cv.wait(lk, [&] { return latch->left == 0; });
 }
 
 static thread_local std::string g_init_err;
