@@ -644,12 +644,12 @@ def main():
         # (products with 2l > 8192 run as several K-chunk launches: count the work per product, not per launch)
         ops_per_product = 36 * 2 * job.rows * job.c * (2 * job.l)
         import mpc_amd
-        nprod = mpc_amd.load_library().mpcx_ring_gemm_products(ctypes.c_uint64(job.rows), ctypes.c_uint64(job.l),
-                                                               ctypes.c_uint64(job.c))
+        # matrix_mul is ONE product of depth 2l (X0 (Y0 + Y1) and X1 Y0 concatenated along K): ask for that shape
         lib = mpc_amd.load_library()
+        dims = (ctypes.c_uint64(job.rows), ctypes.c_uint64(2 * job.l), ctypes.c_uint64(job.c))
+        nprod = lib.mpcx_ring_gemm_products(*dims)
         lib.mpcx_ring_gemm_kernel_name.restype = ctypes.c_char_p
-        kernel = lib.mpcx_ring_gemm_kernel_name(ctypes.c_uint64(job.rows), ctypes.c_uint64(job.l),
-                                                ctypes.c_uint64(job.c)).decode()
+        kernel = lib.mpcx_ring_gemm_kernel_name(*dims).decode()
         avg_s = gemm_ms / gemm_cnt * 1e-3
         achieved = ops_per_product * 3 * args.steps / (gemm_ms * 1e-3) / 1e12
         issued = achieved * nprod / 36

@@ -90,7 +90,7 @@ int mpcx_prg_state_at_pop(mpcx_ctx *ctx, uint64_t seed, uint64_t lcg, uint64_t p
 int mpcx_ring_gemm_u64(mpcx_ctx *ctx, const int64_t *A, const int64_t *B, int64_t *C, uint64_t r, uint64_t l,
                        uint64_t c, int layoutA, int layoutB, int layoutC, int accumulate);
 /* int8 products the library issues per ring multiply-add of an r x l . l x c product: 36 (digit pairs of the
- * positional form) or 18 (residues modulo 18 coprime moduli + CRT), chosen by size; MPCX_GEMM_RNS=0 / 2 in the
+ * positional form) or 18 (residues modulo 18 coprime moduli + CRT), chosen by an estimate of both run times; MPCX_GEMM_RNS=0 / 2 in the
  * environment forces the first / the second.  No counterpart in the reference (Eigen's operator*). */
 int mpcx_ring_gemm_products(uint64_t r, uint64_t l, uint64_t c);
 /* Name of the GEMM kernel such a product runs in ("limb_gemm_kernel", "rns_gemm_kernel": 256 x 256 block tiles,

@@ -175,7 +175,7 @@ int ring_gemm_parts(mpcx_ctx *ctx, const GemmPart *parts, int nparts, u64 r, u64
 // more and use the tail for itself)
 u64 ring_gemm_ws_bytes(int nparts, u64 r, u64 l, u64 c);
 // the same product through a residue number system (ring_gemm_rns.hip): 18 plain int8 products instead of 36
-bool ring_gemm_use_rns(u64 r, u64 l, u64 c);
+bool ring_gemm_use_rns(int nparts, u64 r, u64 l, u64 c);
 bool ring_gemm_rns_wide(); // the residue form's block tile: 384 x 256 (default) or 256 x 256 (MPCX_RNS_TILE=0)
 u32 gemm_group_rows(const char *env_name, u32 tiles_m);
 // looks up, once per device, the address of the file-scope scratch array of the entry point that allocates nothing

@@ -399,7 +399,7 @@ static u64 positional_ws_bytes(int nparts, u64 r, u64 l, u64 c) {
 }
 
 u64 ring_gemm_ws_bytes(int nparts, u64 r, u64 l, u64 c) {
-    if (ring_gemm_use_rns(r, l, c)) return ring_gemm_rns_ws_bytes(nparts, r, l, c);
+    if (ring_gemm_use_rns(nparts, r, l, c)) return ring_gemm_rns_ws_bytes(nparts, r, l, c);
     return positional_ws_bytes(nparts, r, l, c);
 }
 
@@ -408,7 +408,7 @@ static int ring_gemm_positional(mpcx_ctx *ctx, const GemmPart *parts, int nparts
 
 int ring_gemm_parts(mpcx_ctx *ctx, const GemmPart *parts, int nparts, u64 r, u64 l, u64 c, int layA, int layB,
                     const i64 *add, const i64 *sub, i64 *Z, int layZ, int accumulate) {
-    if (r && l && c && ring_gemm_use_rns(r, l, c))
+    if (r && l && c && ring_gemm_use_rns(nparts, r, l, c))
         return ring_gemm_parts_rns(ctx, parts, nparts, r, l, c, layA, layB, add, sub, Z, layZ, accumulate);
     MPCX_REQUIRE(r > 0 && l > 0 && c > 0, "ring gemm: empty operand (r=%llu l=%llu c=%llu)", (unsigned long long)r,
                  (unsigned long long)l, (unsigned long long)c);
@@ -556,9 +556,9 @@ int mpcx_ring_gemm_u64(mpcx_ctx *ctx, const int64_t *A, const int64_t *B, int64_
     return ring_gemm_parts(ctx, &p, 1, r, l, c, layoutA, layoutB, nullptr, nullptr, C, layoutC, accumulate);
 }
 
-int mpcx_ring_gemm_products(uint64_t r, uint64_t l, uint64_t c) { return ring_gemm_use_rns(r, l, c) ? 18 : 36; }
+int mpcx_ring_gemm_products(uint64_t r, uint64_t l, uint64_t c) { return ring_gemm_use_rns(1, r, l, c) ? 18 : 36; }
 const char *mpcx_ring_gemm_kernel_name(uint64_t r, uint64_t l, uint64_t c) {
-    if (!ring_gemm_use_rns(r, l, c)) return "limb_gemm_kernel";
+    if (!ring_gemm_use_rns(1, r, l, c)) return "limb_gemm_kernel";
     return ring_gemm_rns_wide() ? "rns_gemm_wide_kernel" : "rns_gemm_kernel";
 }
 

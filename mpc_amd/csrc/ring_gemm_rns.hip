@@ -621,16 +621,35 @@ u64 rns_part_chunk_len(int nparts, u64 l) {
 
 } // namespace
 
-// MPCX_GEMM_RNS: 0 = never, 2 = every shape, otherwise (default) products large enough for the 18 tiled passes to
-// beat the positional kernel: measured on cubes, 2048^3 0.31 against 0.27 ms, 2560^3 0.52 against 0.59, 4096^3 1.44
-// against 1.85, 6144^3 4.2 against 6.0 (below the crossover the 256 x 256 tiles and the two extra passes cost more than
-// the saved multiplications).  Read on every call so that one process can exercise both paths.
-bool ring_gemm_use_rns(u64 r, u64 l, u64 c) {
+// MPCX_GEMM_RNS: 0 = never, 2 = every shape, otherwise (default) by an estimate of both formulations' times from the
+// rates measured on MI355X (ms; K = words along the contraction over all concatenated parts):
+//   digit pairs: 128 x 64 output tiles, 256 at a time, 5.9e-5 per K and round of tiles (a single round that fills only
+//                part of the chip runs at a higher clock: x (0.6 + 0.4 fill)), + 3.2e-9 per operand word for the digit
+//                split -- 4096 x 8192 x 4096: 3.9, 2048^3: 0.275, 1024 x 2048 x 1024: 0.113;
+//   residues   : 384 x 256 tiles (a last tile row of 128 / 256 rows costs 1/2 / 3/4) x 18 moduli over 256 CUs, + 0.35
+//                rounds for the tail; 2.0e-5 per K + 0.006 (prologue, epilogue) per round; + 5.96e-9 per operand word
+//                for the split + 7.5e-9 per output word for the CRT pass + 0.02 for the two extra launches --
+//                4096 x 8192 x 4096: 2.62, 2048^3: 0.28, 1024 x 2048 x 1024: 0.092.
+// The residue form wins from about 1024 x 2048 x 1024 when K is long and both output dimensions fill tiles; short K
+// (4096 x 1024 x 4096: 0.55 against 0.52) and thin outputs (128 x 8192 x 8192: 0.68 against 0.55) stay with the digit
+// pairs, and so does a tie (5 % margin).  Read on every call so that one process can exercise both paths.
+bool ring_gemm_use_rns(int nparts, u64 r, u64 l, u64 c) {
     const char *e = getenv("MPCX_GEMM_RNS");
     const int mode = e ? atoi(e) : 1;
     if (mode == 0) return false;
     if (mode == 2) return true;
-    return r * c >= 2560ull * 2560ull && l >= 2048;
+    if (r == 0 || l == 0 || c == 0) return false;
+    const double K = (double)nparts * (double)l, words = (double)(r + c) * K;
+    const double tiles_p = (double)ceil_div(r, 128) * (double)ceil_div(c, 64);
+    const double fill = tiles_p < 256.0 ? 0.6 + 0.4 * tiles_p / 256.0 : 1.0;
+    const double t_p = std::ceil(tiles_p / 256.0) * K * 5.9e-5 * fill + words * 3.2e-9;
+    const u64 full = r / 384, rest = ceil_div(r % 384, 128); // whole tile rows, 128-row groups of the last one
+    const double last = rest == 0 ? 0.0 : rest == 1 ? 0.5 : 0.75;
+    const double cols = (double)ceil_div(c, 256);
+    const double wgs = (double)(full + (rest ? 1 : 0)) * cols * 18.0;
+    const double rounds_r = wgs <= 256.0 ? (full ? 1.0 : last) : ((double)full + last) * cols * 18.0 / 256.0 + 0.35;
+    const double t_r = rounds_r * (K * 2.0e-5 + 0.006) + words * 5.96e-9 + (double)r * (double)c * 7.5e-9 + 0.02;
+    return 1.05 * t_r < t_p;
 }
 
 // MPCX_RNS_TILE: 0 = 256 x 256 block tiles, otherwise (default) 384 x 256; read on every call

@@ -188,17 +188,20 @@ def test_aby3_matmul_config5_row_block(env, monkeypatch):
         assert int(P[i, k].item()) % (1 << 64) == want, f"P[{i},{k}] wrong"
 
 
-def test_ring_gemm_at_the_residue_threshold_vs_oracle(env, orc):
-    """The smallest product for which the library picks the residue kernels by itself (2560 x 2048 . 2048 x 2560),
-    word for word against the CPU oracle (row blocks of the oracle's product on eight host threads)."""
+@pytest.mark.parametrize("r,l,c", [(1024, 2048, 1024), (2560, 2048, 2560)])
+def test_ring_gemm_auto_selected_residue_form_vs_oracle(env, orc, r, l, c):
+    """Products for which the library picks the residue kernels by itself (the smallest cube-like shape where its
+    estimate favours them, and the 2560-wide one), word for word against the CPU oracle (row blocks of the oracle's
+    product on eight host threads)."""
     from concurrent.futures import ThreadPoolExecutor
     import mpc_amd
     ctx, torch, dev, _ = env
-    r, l, c = 2560, 2048, 2560
     import ctypes
     nprod = lambda *dims: mpc_amd.load_library().mpcx_ring_gemm_products(*[ctypes.c_uint64(d) for d in dims])
-    assert nprod(r, l, c) == 18 and nprod(r, l - 1, c) == 36
-    rng = np.random.default_rng(2560)
+    assert nprod(r, l, c) == 18
+    # short contractions, thin outputs and small products stay with the digit pairs
+    assert nprod(2560, 512, 2560) == 36 and nprod(128, 8192, 8192) == 36 and nprod(300, 300, 300) == 36
+    rng = np.random.default_rng(r)
     A = rng.integers(-2 ** 63, 2 ** 63, (r, l), dtype=np.int64)
     B = rng.integers(-2 ** 63, 2 ** 63, (l, c), dtype=np.int64)
     dA, dB = torch.from_numpy(A).to(dev), torch.from_numpy(B).to(dev)
