@@ -15,7 +15,9 @@
  *  - calls are asynchronous on the context's HIP stream (mpcx_set_stream / mpcx_sync);
  *  - return value: 0 = ok, non-zero = error (text from mpcx_last_error); shapes are validated on the
  *    host before any kernel is launched;
- *  - one context per engine / host thread; a context is not thread-safe;
+ *  - one context per engine / host thread; a context is not thread-safe; its calls are made with its device
+ *    current on the calling thread (mpcx_init leaves it so; a thread that drives contexts of several devices calls
+ *    hipSetDevice before switching, or uses the mpcx_group_* calls, whose worker threads are bound to their devices);
  *  - PRG streams are named by the PRgenerator seed (lcg is 0 in both engines,
  *    mpc_engine/ABY3Engine.cpp:34-53).  "pop index" k = the k-th pop_int64()/pop_bool() after
  *    construction (utils/PRgenerator.cpp:34-42); "buffer index" i = int_buff[i] / bool_buff[i]
