@@ -1,15 +1,19 @@
 #include "SecurennEngine.hpp"
 
+#include <memory>
+
 #include "../utils/util.hpp"
 #include "gpu_support.hpp"
 
 using mpcgpu::Dev;
 using mpcgpu::upload_string;
+using mpcgpu::upload_string_at;
 
 namespace {
 const size_t W = sizeof(int64_t);
 const size_t ZP = sizeof(zpshare); // 128 bytes per element
 inline void append(string &dst, const string &src) { dst.append(src); }
+void vector_mul_impl(SecurennEngine &e, const vector<int64_t> &Xj, const vector<int64_t> &Yj, vector<int64_t> &Zj);
 } // namespace
 
 SecurennEngine::SecurennEngine(VirtuleMessenger *_messenger, size_t _party_id)
@@ -19,10 +23,16 @@ SecurennEngine::SecurennEngine(VirtuleMessenger *_messenger, size_t _party_id)
     static const uint64_t pair_key[3][3] = {{KEY0, KEY01, KEY20}, {KEY01, KEY1, KEY12}, {KEY20, KEY12, KEY2}};
     assert(party_id < 3);
     for (size_t k = 0; k < 3; k++) prgs.push_back(PRgenerator(pair_key[party_id][k], 0));
-    gpu = mpcgpu::open_context();
+    group = mpcgpu::open_group();
+    gpu = group ? mpcx_group_ctx(group, 0) : mpcgpu::open_context();
 }
 
-SecurennEngine::~SecurennEngine() { mpcx_shutdown(gpu); }
+SecurennEngine::~SecurennEngine() {
+    if (group)
+        mpcx_group_shutdown(group);
+    else
+        mpcx_shutdown(gpu);
+}
 
 // ---- Beaver-triple matrix product: party 2 deals (A_i | B_i | C_i), parties 0/1 open E = X - A, F = Y - B
 void SecurennEngine::matrix_mul(const MatrixXl &Xj, const MatrixXl &Yj, MatrixXl &Zj) {
@@ -84,36 +94,7 @@ void SecurennEngine::vector_mul(const vector<int64_t> &Xj, const vector<int64_t>
     const size_t n = Xj.size();
     assert(Yj.size() == n);
     Zj.assign(n, 0);
-    if (party_id == 2) {
-        Dev<int64_t> t0(gpu, 3 * n), t1(gpu, 3 * n); // A_i | B_i | C_i
-        GPU_OK(gpu, mpcx_snn_beaver_dealer_vecmul(gpu, prgs[2].init_seed, n, 0, n, t0.p, t0.p + n, t0.p + 2 * n, t1.p,
-                                                  t1.p + n, t1.p + 2 * n));
-        t0.to_string(message_send[0]);
-        t1.to_string(message_send[1]);
-        messenger->send_and_recv(message_send, message_recv); // round 1
-        message_send[0].clear();
-        message_send[1].clear();
-        messenger->send_and_recv(message_send, message_recv); // round 2
-        return;
-    }
-    const size_t peer = 1 - party_id;
-    for (auto &m : message_send) m.clear();
-    messenger->send_and_recv(message_send, message_recv); // round 1
-    MSG_CHECK(message_recv[2].size() == 3 * n * W);
-    Dev<int64_t> t(gpu, 3 * n), ef(gpu, 2 * n), efp(gpu, 2 * n), z(gpu, n);
-    upload_string(t, message_recv[2]);
-    {
-        Dev<int64_t> x(gpu, Xj.data(), n), y(gpu, Yj.data(), n);
-        GPU_OK(gpu, mpcx_snn_beaver_party_open_vecmul(gpu, x, y, t.p, t.p + n, n, ef.p, ef.p + n));
-    }
-    ef.to_string(message_send[peer]);
-    message_send[2].clear();
-    messenger->send_and_recv(message_send, message_recv); // round 2
-    MSG_CHECK(message_recv[peer].size() == 2 * n * W);
-    upload_string(efp, message_recv[peer]);
-    GPU_OK(gpu, mpcx_snn_beaver_party_finish_vecmul(gpu, (int)party_id, t.p, t.p + n, t.p + 2 * n, ef.p, ef.p + n,
-                                                    efp.p, efp.p + n, n, z));
-    z.down(Zj.data(), n);
+    vector_mul_impl(*this, Xj, Yj, Zj);
 }
 
 // ---- additive sharing between parties 0 and 1 out of their common stream
@@ -254,84 +235,154 @@ void SecurennEngine::reveal_zp(const vector<zpshare> &Xbits_j, vector<zpshare> &
 // The multi-round protocols below keep every intermediate value on the device: a message is downloaded once
 // into its send slot and a received message uploaded once; the public methods only move their arguments in and
 // their results out.  (`e` is the engine; these helpers are file-local so the class keeps the reference's surface.)
+//
+// Every protocol is written over element ranges: run() hands the whole vector to the engine's one GPU, or -- with
+// MPCX_DEVICES -- every member of the group its own contiguous range [first, first + count) on the member's thread.
+// A member keeps its device buffers across the rounds (one slot per member in the vectors below), runs the range
+// forms (n_total, i0, n) of the library's segments and moves its own slices of the messages: a message is the
+// concatenation of sections (one per array it carries), each section holding the elements in order.
 namespace {
 
+const uint64_t RANGE_GRANULE = 64;
+template <class T> using Buf = std::unique_ptr<Dev<T>>;
+template <class T> using Bufs = vector<Buf<T>>;
+
+template <class F> void run(SecurennEngine &e, size_t n, F f) {
+    if (e.group && n)
+        mpcgpu::group_for_each(e.group, n, RANGE_GRANULE, f);
+    else
+        f(e.gpu, 0, (uint64_t)0, (uint64_t)n);
+}
+size_t members(const SecurennEngine &e) { return e.group ? (size_t)mpcx_group_size(e.group) : 1; }
+template <class T> Dev<T> &fresh(Buf<T> &b, mpcx_ctx *ctx, size_t count) {
+    b.reset(new Dev<T>(ctx, count));
+    return *b;
+}
+// `count` elements of `per` items each, from item dev_first of the buffer, into / out of the section that starts at
+// byte `section` of the message, at element `first`
+template <class T>
+void put(const Dev<T> &d, string &msg, size_t section, size_t first, size_t count, size_t per = 1, size_t dev_first = 0) {
+    if (count) d.down(&msg[section + first * per * sizeof(T)], count * per, dev_first);
+}
+template <class T>
+void get(Dev<T> &d, const string &msg, size_t section, size_t first, size_t count, size_t per = 1, size_t dev_first = 0) {
+    upload_string_at(d, dev_first, msg, section + first * per * sizeof(T), count * per * sizeof(T));
+}
+
+struct PcIn { // what a party brings to privateCompare, per member
+    Bufs<uint16_t> xbits;
+    Bufs<int8_t> beta;
+    Bufs<int64_t> r;
+    explicit PcIn(size_t m) : xbits(m), beta(m), r(m) {}
+};
+
 // privateCompare, parties 0/1 (one round): d -> party 2
-void pc_party_dev(SecurennEngine &e, const Dev<uint16_t> &xbits, const Dev<int8_t> &beta, const Dev<int64_t> &r, size_t n) {
-    Dev<uint16_t> d(e.gpu, 64 * n);
-    GPU_OK(e.gpu, mpcx_snn_pc_party(e.gpu, (int)e.party_id, xbits, beta, r, n, 0, n, e.prgs[1 - e.party_id].init_seed, d));
+void pc_party_dev(SecurennEngine &e, const PcIn &in, size_t n) {
+    const uint64_t s01 = e.prgs[1 - e.party_id].init_seed;
     e.message_send[1 - e.party_id].clear();
-    d.to_string(e.message_send[2]);
+    string &out = e.message_send[2];
+    out.resize(n * ZP);
+    run(e, n, [&](mpcx_ctx *ctx, int m, uint64_t i0, uint64_t cnt) {
+        Dev<uint16_t> d(ctx, 64 * cnt);
+        GPU_OK(ctx, mpcx_snn_pc_party(ctx, (int)e.party_id, in.xbits[m]->p, in.beta[m]->p, in.r[m]->p, n, i0, cnt, s01, d));
+        put(d, out, 0, i0, cnt, 64);
+    });
     e.messenger->send_and_recv(e.message_send, e.message_recv);
 }
 // privateCompare, party 2 (one round): beta' on the device
-void pc_helper_dev(SecurennEngine &e, size_t n, Dev<int8_t> &beta2) {
+void pc_helper_dev(SecurennEngine &e, size_t n, Bufs<int8_t> &beta2) {
     e.message_send[0].clear();
     e.message_send[1].clear();
     e.messenger->send_and_recv(e.message_send, e.message_recv);
     MSG_CHECK(e.message_recv[0].size() == n * ZP && e.message_recv[1].size() == n * ZP);
-    Dev<uint16_t> d0(e.gpu, 64 * n), d1(e.gpu, 64 * n);
-    upload_string(d0, e.message_recv[0]);
-    upload_string(d1, e.message_recv[1]);
-    GPU_OK(e.gpu, mpcx_snn_pc_helper(e.gpu, d0, d1, n, beta2));
+    run(e, n, [&](mpcx_ctx *ctx, int m, uint64_t i0, uint64_t cnt) {
+        Dev<uint16_t> d0(ctx, 64 * cnt), d1(ctx, 64 * cnt);
+        get(d0, e.message_recv[0], 0, i0, cnt, 64);
+        get(d1, e.message_recv[1], 0, i0, cnt, 64);
+        GPU_OK(ctx, mpcx_snn_pc_helper(ctx, d0, d1, cnt, fresh(beta2[m], ctx, cnt)));
+    });
 }
-// vector_mul, party 2 (two rounds)
+// vector_mul, party 2 (two rounds): A_i | B_i | C_i to party i
 void vecmul_dealer(SecurennEngine &e, size_t n) {
-    Dev<int64_t> t0(e.gpu, 3 * n), t1(e.gpu, 3 * n); // A_i | B_i | C_i
-    GPU_OK(e.gpu, mpcx_snn_beaver_dealer_vecmul(e.gpu, e.prgs[2].init_seed, n, 0, n, t0.p, t0.p + n, t0.p + 2 * n, t1.p,
-                                                t1.p + n, t1.p + 2 * n));
-    t0.to_string(e.message_send[0]);
-    t1.to_string(e.message_send[1]);
+    for (size_t j = 0; j < 2; j++) e.message_send[j].resize(3 * n * W);
+    run(e, n, [&](mpcx_ctx *ctx, int, uint64_t i0, uint64_t cnt) {
+        Dev<int64_t> t0(ctx, 3 * cnt), t1(ctx, 3 * cnt);
+        GPU_OK(ctx, mpcx_snn_beaver_dealer_vecmul(ctx, e.prgs[2].init_seed, n, i0, cnt, t0.p, t0.p + cnt, t0.p + 2 * cnt, t1.p,
+                                                  t1.p + cnt, t1.p + 2 * cnt));
+        for (size_t k = 0; k < 3; k++) {
+            put(t0, e.message_send[0], k * n * W, i0, cnt, 1, k * cnt);
+            put(t1, e.message_send[1], k * n * W, i0, cnt, 1, k * cnt);
+        }
+    });
     e.messenger->send_and_recv(e.message_send, e.message_recv); // round 1
     e.message_send[0].clear();
     e.message_send[1].clear();
     e.messenger->send_and_recv(e.message_send, e.message_recv); // round 2
 }
 // vector_mul, parties 0/1 (two rounds): z = share of x * y
-void vecmul_party_dev(SecurennEngine &e, const Dev<int64_t> &x, const Dev<int64_t> &y, size_t n, Dev<int64_t> &z) {
-    const size_t peer = 1 - e.party_id;
+void vecmul_party_dev(SecurennEngine &e, const Bufs<int64_t> &x, const Bufs<int64_t> &y, size_t n, Bufs<int64_t> &z) {
+    const size_t peer = 1 - e.party_id, G = members(e);
     for (auto &m : e.message_send) m.clear();
     e.messenger->send_and_recv(e.message_send, e.message_recv); // round 1
     MSG_CHECK(e.message_recv[2].size() == 3 * n * W);
-    Dev<int64_t> t(e.gpu, 3 * n), ef(e.gpu, 2 * n), efp(e.gpu, 2 * n);
-    upload_string(t, e.message_recv[2]);
-    GPU_OK(e.gpu, mpcx_snn_beaver_party_open_vecmul(e.gpu, x, y, t.p, t.p + n, n, ef.p, ef.p + n));
-    ef.to_string(e.message_send[peer]);
+    Bufs<int64_t> t(G), ef(G);
+    string &out = e.message_send[peer];
+    out.resize(2 * n * W);
+    run(e, n, [&](mpcx_ctx *ctx, int m, uint64_t i0, uint64_t cnt) {
+        Dev<int64_t> &tm = fresh(t[m], ctx, 3 * cnt), &efm = fresh(ef[m], ctx, 2 * cnt);
+        for (size_t k = 0; k < 3; k++) get(tm, e.message_recv[2], k * n * W, i0, cnt, 1, k * cnt);
+        GPU_OK(ctx, mpcx_snn_beaver_party_open_vecmul(ctx, x[m]->p, y[m]->p, tm.p, tm.p + cnt, cnt, efm.p, efm.p + cnt));
+        put(efm, out, 0, i0, cnt, 1, 0);
+        put(efm, out, n * W, i0, cnt, 1, cnt);
+    });
     e.message_send[2].clear();
     e.messenger->send_and_recv(e.message_send, e.message_recv); // round 2
     MSG_CHECK(e.message_recv[peer].size() == 2 * n * W);
-    upload_string(efp, e.message_recv[peer]);
-    GPU_OK(e.gpu, mpcx_snn_beaver_party_finish_vecmul(e.gpu, (int)e.party_id, t.p, t.p + n, t.p + 2 * n, ef.p, ef.p + n,
-                                                      efp.p, efp.p + n, n, z));
+    run(e, n, [&](mpcx_ctx *ctx, int m, uint64_t i0, uint64_t cnt) {
+        Dev<int64_t> efp(ctx, 2 * cnt);
+        get(efp, e.message_recv[peer], 0, i0, cnt, 1, 0);
+        get(efp, e.message_recv[peer], n * W, i0, cnt, 1, cnt);
+        Dev<int64_t> &tm = *t[m], &efm = *ef[m];
+        GPU_OK(ctx, mpcx_snn_beaver_party_finish_vecmul(ctx, (int)e.party_id, tm.p, tm.p + cnt, tm.p + 2 * cnt, efm.p,
+                                                        efm.p + cnt, efp.p, efp.p + cnt, cnt, fresh(z[m], ctx, cnt)));
+    });
 }
 
 // shareConvert (four rounds); parties 0/1: a -> y, party 2: no input, no output
-void share_convert_dev(SecurennEngine &e, const Dev<int64_t> *a, size_t n, Dev<int64_t> *y) {
-    mpcx_ctx *gpu = e.gpu;
+void share_convert_dev(SecurennEngine &e, const Bufs<int64_t> *a, size_t n, Bufs<int64_t> *y) {
+    const size_t G = members(e);
     if (e.party_id != 2) {
         const size_t peer = 1 - e.party_id;
         const uint64_t s01 = e.prgs[peer].init_seed;
-        Dev<int64_t> x(gpu, n);
-        GPU_OK(gpu, mpcx_snn_sc_party_open(gpu, (int)e.party_id, *a, n, 0, n, s01, x));
         e.message_send[peer].clear();
-        x.to_string(e.message_send[2]);
+        e.message_send[2].resize(n * W);
+        run(e, n, [&](mpcx_ctx *ctx, int m, uint64_t i0, uint64_t cnt) {
+            Dev<int64_t> x(ctx, cnt);
+            GPU_OK(ctx, mpcx_snn_sc_party_open(ctx, (int)e.party_id, (*a)[m]->p, n, i0, cnt, s01, x));
+            put(x, e.message_send[2], 0, i0, cnt);
+        });
         e.messenger->send_and_recv(e.message_send, e.message_recv); // round 1
         e.message_send[2].clear();
         e.messenger->send_and_recv(e.message_send, e.message_recv); // round 2: x bits over Z_67 | delta_j
         MSG_CHECK(e.message_recv[2].size() == n * (ZP + W));
-        Dev<uint16_t> xbits(gpu, 64 * n);
-        Dev<int64_t> delta(gpu, n), rm1(gpu, n), eta1(gpu, n);
-        Dev<int8_t> eta2(gpu, n);
-        upload_string(xbits, e.message_recv[2], 0, n * ZP);
-        upload_string(delta, e.message_recv[2], n * ZP, n * W);
-        GPU_OK(gpu, mpcx_snn_sc_party_pc_inputs(gpu, n, 0, n, s01, eta2, rm1));
-        pc_party_dev(e, xbits, eta2, rm1, n); // round 3
+        PcIn pc(G);
+        Bufs<int64_t> delta(G);
+        run(e, n, [&](mpcx_ctx *ctx, int m, uint64_t i0, uint64_t cnt) {
+            get(fresh(pc.xbits[m], ctx, 64 * cnt), e.message_recv[2], 0, i0, cnt, 64);
+            get(fresh(delta[m], ctx, cnt), e.message_recv[2], n * ZP, i0, cnt);
+            GPU_OK(ctx, mpcx_snn_sc_party_pc_inputs(ctx, n, i0, cnt, s01, fresh(pc.beta[m], ctx, cnt), fresh(pc.r[m], ctx, cnt)));
+        });
+        pc_party_dev(e, pc, n); // round 3
         e.message_send[peer].clear();
         e.message_send[2].clear();
         e.messenger->send_and_recv(e.message_send, e.message_recv); // round 4: eta'_j
         MSG_CHECK(e.message_recv[2].size() == n * W);
-        upload_string(eta1, e.message_recv[2]);
-        GPU_OK(gpu, mpcx_snn_sc_party_finish(gpu, (int)e.party_id, *a, delta, eta1, n, 0, n, s01, *y));
+        run(e, n, [&](mpcx_ctx *ctx, int m, uint64_t i0, uint64_t cnt) {
+            Dev<int64_t> eta1(ctx, cnt);
+            get(eta1, e.message_recv[2], 0, i0, cnt);
+            GPU_OK(ctx, mpcx_snn_sc_party_finish(ctx, (int)e.party_id, (*a)[m]->p, delta[m]->p, eta1, n, i0, cnt, s01,
+                                                 fresh((*y)[m], ctx, cnt)));
+        });
         return;
     }
     const uint64_t sS = e.prgs[2].init_seed;
@@ -339,58 +390,61 @@ void share_convert_dev(SecurennEngine &e, const Dev<int64_t> *a, size_t n, Dev<i
     e.message_send[1].clear();
     e.messenger->send_and_recv(e.message_send, e.message_recv); // round 1
     MSG_CHECK(e.message_recv[0].size() == n * W && e.message_recv[1].size() == n * W);
-    {
-        Dev<int64_t> x0(gpu, n), x1(gpu, n), d0(gpu, n), d1(gpu, n);
-        Dev<uint16_t> xb0(gpu, 64 * n), xb1(gpu, 64 * n);
-        upload_string(x0, e.message_recv[0]);
-        upload_string(x1, e.message_recv[1]);
-        GPU_OK(gpu, mpcx_snn_sc_helper_split(gpu, x0, x1, n, 0, n, sS, xb0, d0, xb1, d1));
-        for (size_t j = 0; j < 2; j++) { // bit shares | delta_j
-            e.message_send[j].resize(n * (ZP + W));
-            if (n) {
-                (j ? xb1 : xb0).down(&e.message_send[j][0], 64 * n);
-                (j ? d1 : d0).down(&e.message_send[j][n * ZP], n);
-            }
-        }
-    }
+    for (size_t j = 0; j < 2; j++) e.message_send[j].resize(n * (ZP + W)); // bit shares | delta_j
+    run(e, n, [&](mpcx_ctx *ctx, int, uint64_t i0, uint64_t cnt) {
+        Dev<int64_t> x0(ctx, cnt), x1(ctx, cnt), d0(ctx, cnt), d1(ctx, cnt);
+        Dev<uint16_t> xb0(ctx, 64 * cnt), xb1(ctx, 64 * cnt);
+        get(x0, e.message_recv[0], 0, i0, cnt);
+        get(x1, e.message_recv[1], 0, i0, cnt);
+        GPU_OK(ctx, mpcx_snn_sc_helper_split(ctx, x0, x1, n, i0, cnt, sS, xb0, d0, xb1, d1));
+        put(xb0, e.message_send[0], 0, i0, cnt, 64);
+        put(d0, e.message_send[0], n * ZP, i0, cnt);
+        put(xb1, e.message_send[1], 0, i0, cnt, 64);
+        put(d1, e.message_send[1], n * ZP, i0, cnt);
+    });
     e.messenger->send_and_recv(e.message_send, e.message_recv); // round 2
-    Dev<int8_t> eta1_plain(gpu, n);
+    Bufs<int8_t> eta1_plain(G);
     pc_helper_dev(e, n, eta1_plain); // round 3
-    Dev<int64_t> e0(gpu, n), e1(gpu, n);
-    GPU_OK(gpu, mpcx_snn_sc_helper_eta(gpu, eta1_plain, n, 0, n, sS, e0, e1));
-    e0.to_string(e.message_send[0]);
-    e1.to_string(e.message_send[1]);
+    for (size_t j = 0; j < 2; j++) e.message_send[j].resize(n * W);
+    run(e, n, [&](mpcx_ctx *ctx, int m, uint64_t i0, uint64_t cnt) {
+        Dev<int64_t> e0(ctx, cnt), e1(ctx, cnt);
+        GPU_OK(ctx, mpcx_snn_sc_helper_eta(ctx, eta1_plain[m]->p, n, i0, cnt, sS, e0, e1));
+        put(e0, e.message_send[0], 0, i0, cnt);
+        put(e1, e.message_send[1], 0, i0, cnt);
+    });
     e.messenger->send_and_recv(e.message_send, e.message_recv); // round 4
 }
 
 // msb over Z_{2^64-1} (= lsb of 2a), result shared over Z_2^64; six rounds
-void msb_L1_dev(SecurennEngine &e, const Dev<int64_t> *a, size_t n, Dev<int64_t> *b) {
-    mpcx_ctx *gpu = e.gpu;
+void msb_L1_dev(SecurennEngine &e, const Bufs<int64_t> *a, size_t n, Bufs<int64_t> *b) {
+    const size_t G = members(e);
     if (e.party_id == 2) {
         const uint64_t sS = e.prgs[2].init_seed;
-        {
-            Dev<int64_t> x0(gpu, n), l0(gpu, n), x1(gpu, n), l1(gpu, n);
-            Dev<uint16_t> xb0(gpu, 64 * n), xb1(gpu, 64 * n);
-            GPU_OK(gpu, mpcx_snn_msbl1_helper_deal(gpu, n, 0, n, sS, x0, l0, xb0, x1, l1, xb1));
-            for (size_t j = 0; j < 2; j++) { // x_j | lsb(x)_j | bits of x over Z_67
-                e.message_send[j].resize(n * (2 * W + ZP));
-                if (n) {
-                    (j ? x1 : x0).down(&e.message_send[j][0], n);
-                    (j ? l1 : l0).down(&e.message_send[j][n * W], n);
-                    (j ? xb1 : xb0).down(&e.message_send[j][2 * n * W], 64 * n);
-                }
-            }
-        }
+        for (size_t j = 0; j < 2; j++) e.message_send[j].resize(n * (2 * W + ZP)); // x_j | lsb(x)_j | bits of x over Z_67
+        run(e, n, [&](mpcx_ctx *ctx, int, uint64_t i0, uint64_t cnt) {
+            Dev<int64_t> x0(ctx, cnt), l0(ctx, cnt), x1(ctx, cnt), l1(ctx, cnt);
+            Dev<uint16_t> xb0(ctx, 64 * cnt), xb1(ctx, 64 * cnt);
+            GPU_OK(ctx, mpcx_snn_msbl1_helper_deal(ctx, n, i0, cnt, sS, x0, l0, xb0, x1, l1, xb1));
+            put(x0, e.message_send[0], 0, i0, cnt);
+            put(l0, e.message_send[0], n * W, i0, cnt);
+            put(xb0, e.message_send[0], 2 * n * W, i0, cnt, 64);
+            put(x1, e.message_send[1], 0, i0, cnt);
+            put(l1, e.message_send[1], n * W, i0, cnt);
+            put(xb1, e.message_send[1], 2 * n * W, i0, cnt, 64);
+        });
         e.messenger->send_and_recv(e.message_send, e.message_recv); // round 1
         e.message_send[0].clear();
         e.message_send[1].clear();
         e.messenger->send_and_recv(e.message_send, e.message_recv); // round 2
-        Dev<int8_t> beta1_plain(gpu, n);
+        Bufs<int8_t> beta1_plain(G);
         pc_helper_dev(e, n, beta1_plain); // round 3
-        Dev<int64_t> b0(gpu, n), b1(gpu, n);
-        GPU_OK(gpu, mpcx_snn_msbl1_helper_beta(gpu, beta1_plain, n, 0, n, sS, b0, b1));
-        b0.to_string(e.message_send[0]);
-        b1.to_string(e.message_send[1]);
+        for (size_t j = 0; j < 2; j++) e.message_send[j].resize(n * W);
+        run(e, n, [&](mpcx_ctx *ctx, int m, uint64_t i0, uint64_t cnt) {
+            Dev<int64_t> b0(ctx, cnt), b1(ctx, cnt);
+            GPU_OK(ctx, mpcx_snn_msbl1_helper_beta(ctx, beta1_plain[m]->p, n, i0, cnt, sS, b0, b1));
+            put(b0, e.message_send[0], 0, i0, cnt);
+            put(b1, e.message_send[1], 0, i0, cnt);
+        });
         e.messenger->send_and_recv(e.message_send, e.message_recv); // round 4
         vecmul_dealer(e, n);                                        // rounds 5-6
         return;
@@ -401,28 +455,61 @@ void msb_L1_dev(SecurennEngine &e, const Dev<int64_t> *a, size_t n, Dev<int64_t>
     e.message_send[peer].clear();
     e.messenger->send_and_recv(e.message_send, e.message_recv); // round 1
     MSG_CHECK(e.message_recv[2].size() == n * (2 * W + ZP));
-    Dev<int64_t> xj(gpu, n), xlsb(gpu, n), rj(gpu, n), rpeer(gpu, n), R(gpu, n);
-    Dev<uint16_t> xbits(gpu, 64 * n);
-    upload_string(xj, e.message_recv[2], 0, n * W);
-    upload_string(xlsb, e.message_recv[2], n * W, n * W);
-    upload_string(xbits, e.message_recv[2], 2 * n * W, n * ZP);
-    GPU_OK(gpu, mpcx_snn_msbl1_party_open(gpu, *a, xj, n, rj));
-    rj.to_string(e.message_send[peer]);
+    PcIn pc(G);
+    Bufs<int64_t> xlsb(G), rj(G);
+    e.message_send[peer].resize(n * W);
+    run(e, n, [&](mpcx_ctx *ctx, int m, uint64_t i0, uint64_t cnt) {
+        Dev<int64_t> xj(ctx, cnt);
+        get(xj, e.message_recv[2], 0, i0, cnt);
+        get(fresh(xlsb[m], ctx, cnt), e.message_recv[2], n * W, i0, cnt);
+        get(fresh(pc.xbits[m], ctx, 64 * cnt), e.message_recv[2], 2 * n * W, i0, cnt, 64);
+        GPU_OK(ctx, mpcx_snn_msbl1_party_open(ctx, (*a)[m]->p, xj, cnt, fresh(rj[m], ctx, cnt)));
+        put(*rj[m], e.message_send[peer], 0, i0, cnt);
+    });
     e.messenger->send_and_recv(e.message_send, e.message_recv); // round 2: open r = 2a + x
     MSG_CHECK(e.message_recv[peer].size() == n * W);
-    upload_string(rpeer, e.message_recv[peer]);
-    Dev<int8_t> beta0(gpu, n);
-    GPU_OK(gpu, mpcx_snn_msbl1_party_pc_inputs(gpu, rj, rpeer, 0, n, s01, beta0, R));
-    pc_party_dev(e, xbits, beta0, R, n); // round 3
+    run(e, n, [&](mpcx_ctx *ctx, int m, uint64_t i0, uint64_t cnt) {
+        Dev<int64_t> rpeer(ctx, cnt);
+        get(rpeer, e.message_recv[peer], 0, i0, cnt);
+        GPU_OK(ctx, mpcx_snn_msbl1_party_pc_inputs(ctx, rj[m]->p, rpeer, i0, cnt, s01, fresh(pc.beta[m], ctx, cnt),
+                                                   fresh(pc.r[m], ctx, cnt)));
+    });
+    pc_party_dev(e, pc, n); // round 3
     e.message_send[2].clear();
     e.message_send[peer].clear();
     e.messenger->send_and_recv(e.message_send, e.message_recv); // round 4: share of beta'
     MSG_CHECK(e.message_recv[2].size() == n * W);
-    Dev<int64_t> beta1(gpu, n), gamma(gpu, n), delta(gpu, n), theta(gpu, n);
-    upload_string(beta1, e.message_recv[2]);
-    GPU_OK(gpu, mpcx_snn_msbl1_party_mid(gpu, (int)e.party_id, beta1, xlsb, beta0, R, n, gamma, delta));
+    Bufs<int64_t> gamma(G), delta(G), theta(G);
+    run(e, n, [&](mpcx_ctx *ctx, int m, uint64_t i0, uint64_t cnt) {
+        Dev<int64_t> beta1(ctx, cnt);
+        get(beta1, e.message_recv[2], 0, i0, cnt);
+        GPU_OK(ctx, mpcx_snn_msbl1_party_mid(ctx, (int)e.party_id, beta1, xlsb[m]->p, pc.beta[m]->p, pc.r[m]->p, cnt,
+                                             fresh(gamma[m], ctx, cnt), fresh(delta[m], ctx, cnt)));
+    });
     vecmul_party_dev(e, gamma, delta, n, theta); // rounds 5-6
-    GPU_OK(gpu, mpcx_snn_msbl1_party_finish(gpu, gamma, delta, theta, n, *b));
+    run(e, n, [&](mpcx_ctx *ctx, int m, uint64_t, uint64_t cnt) {
+        GPU_OK(ctx, mpcx_snn_msbl1_party_finish(ctx, gamma[m]->p, delta[m]->p, theta[m]->p, cnt, fresh((*b)[m], ctx, cnt)));
+    });
+}
+
+// host vector -> one device buffer per member, and back
+template <class T> void scatter(SecurennEngine &e, const T *host, size_t n, size_t per, Bufs<T> &d) {
+    run(e, n, [&](mpcx_ctx *ctx, int m, uint64_t i0, uint64_t cnt) { fresh(d[m], ctx, per * cnt).up(host + per * i0, per * cnt); });
+}
+template <class T> void gather(SecurennEngine &e, const Bufs<T> &d, size_t n, T *host) {
+    run(e, n, [&](mpcx_ctx *, int m, uint64_t i0, uint64_t cnt) {
+        if (cnt) d[m]->down(host + i0, cnt);
+    });
+}
+
+void vector_mul_impl(SecurennEngine &e, const vector<int64_t> &Xj, const vector<int64_t> &Yj, vector<int64_t> &Zj) {
+    const size_t n = Xj.size(), G = members(e);
+    if (e.party_id == 2) return vecmul_dealer(e, n);
+    Bufs<int64_t> x(G), y(G), z(G);
+    scatter(e, Xj.data(), n, 1, x);
+    scatter(e, Yj.data(), n, 1, y);
+    vecmul_party_dev(e, x, y, n, z);
+    gather(e, z, n, Zj.data());
 }
 
 } // namespace
@@ -430,19 +517,20 @@ void msb_L1_dev(SecurennEngine &e, const Dev<int64_t> *a, size_t n, Dev<int64_t>
 // ---- privateCompare: parties 0/1 send masked difference digits to party 2, which learns beta' = beta xor (x > r)
 void SecurennEngine::privateCompare(const vector<zpshare> &Xbits_j, const vector<int8_t> &Beta1_plain,
                                     const vector<int64_t> &R_palin, vector<int8_t> &Beta2_plain) {
-    const size_t n = Xbits_j.size();
+    const size_t n = Xbits_j.size(), G = members(*this);
     assert(Beta1_plain.size() == n && R_palin.size() == n);
     Beta2_plain.assign(n, 0);
     if (party_id != 2) {
-        Dev<uint16_t> xb(gpu, (const uint16_t *)Xbits_j.data(), 64 * n);
-        Dev<int8_t> beta(gpu, Beta1_plain.data(), n);
-        Dev<int64_t> r(gpu, R_palin.data(), n);
-        pc_party_dev(*this, xb, beta, r, n);
+        PcIn pc(G);
+        scatter(*this, (const uint16_t *)Xbits_j.data(), n, 64, pc.xbits);
+        scatter(*this, Beta1_plain.data(), n, 1, pc.beta);
+        scatter(*this, R_palin.data(), n, 1, pc.r);
+        pc_party_dev(*this, pc, n);
         return;
     }
-    Dev<int8_t> b(gpu, n);
+    Bufs<int8_t> b(G);
     pc_helper_dev(*this, n, b);
-    b.down(Beta2_plain.data(), n);
+    gather(*this, b, n, Beta2_plain.data());
 }
 
 // ---- shareConvert: shares over Z_2^64 -> shares over Z_{2^64-1}, four rounds
@@ -455,15 +543,16 @@ void SecurennEngine::shareConvert(const vector<int64_t> &Aj, vector<int64_t> &Yj
         for (size_t i = 0; i < ad.size(); i++) assert((uint64_t)yd[i] == (uint64_t)ad[i] % L_1);
     });
 #endif
-    const size_t n = Aj.size();
+    const size_t n = Aj.size(), G = members(*this);
     Yj.assign(n, 0);
     if (party_id == 2) {
         share_convert_dev(*this, nullptr, n, nullptr);
         return;
     }
-    Dev<int64_t> a(gpu, Aj.data(), n), y(gpu, n);
+    Bufs<int64_t> a(G), y(G);
+    scatter(*this, Aj.data(), n, 1, a);
     share_convert_dev(*this, &a, n, &y);
-    y.down(Yj.data(), n);
+    gather(*this, y, n, Yj.data());
 }
 
 // ---- msb over Z_{2^64-1}, six rounds
@@ -476,15 +565,16 @@ void SecurennEngine::msb_L_1(const vector<int64_t> &Aj, vector<int64_t> &Bj) {
         for (size_t i = 0; i < ad.size(); i++) assert((uint64_t)bd[i] == (uint64_t)ad[i] >> 63);
     });
 #endif
-    const size_t n = Aj.size();
+    const size_t n = Aj.size(), G = members(*this);
     Bj.assign(n, 0);
     if (party_id == 2) {
         msb_L1_dev(*this, nullptr, n, nullptr);
         return;
     }
-    Dev<int64_t> a(gpu, Aj.data(), n), b(gpu, n);
+    Bufs<int64_t> a(G), b(G);
+    scatter(*this, Aj.data(), n, 1, a);
     msb_L1_dev(*this, &a, n, &b);
-    b.down(Bj.data(), n);
+    gather(*this, b, n, Bj.data());
 }
 
 // ---- msb of a in [-2^62, 2^62): convert 2a to Z_{2^64-1}, then msb_L_1; the intermediate stays on the device
@@ -500,16 +590,19 @@ void SecurennEngine::msb(const vector<int64_t> &Aj, vector<int64_t> &Bj) {
         }
     });
 #endif
-    const size_t n = Aj.size();
+    const size_t n = Aj.size(), G = members(*this);
     Bj.assign(n, 0);
     if (party_id == 2) {
         share_convert_dev(*this, nullptr, n, nullptr);
         msb_L1_dev(*this, nullptr, n, nullptr);
         return;
     }
-    Dev<int64_t> a(gpu, Aj.data(), n), twoA(gpu, n), y(gpu, n), b(gpu, n);
-    GPU_OK(gpu, mpcx_ring_shl1(gpu, a, twoA, n));
+    Bufs<int64_t> a(G), twoA(G), y(G), b(G);
+    scatter(*this, Aj.data(), n, 1, a);
+    run(*this, n, [&](mpcx_ctx *ctx, int m, uint64_t, uint64_t cnt) {
+        GPU_OK(ctx, mpcx_ring_shl1(ctx, a[m]->p, fresh(twoA[m], ctx, cnt), cnt));
+    });
     share_convert_dev(*this, &twoA, n, &y);
     msb_L1_dev(*this, &y, n, &b);
-    b.down(Bj.data(), n);
+    gather(*this, b, n, Bj.data());
 }

@@ -30,6 +30,7 @@ using MatrixXl = Eigen::Matrix<int64_t, Eigen::Dynamic, Eigen::Dynamic>;
 using zpshare = std::array<uint16_t, 64>; // Z_67 shares of the 64 bits of one element, least significant first
 
 struct mpcx_ctx;
+struct mpcx_group;
 
 class SecurennEngine {
   public:
@@ -47,6 +48,7 @@ class SecurennEngine {
     vector<string> message_send;
     vector<string> message_recv;
     mpcx_ctx *gpu;               // this engine's GPU context (an addition)
+    mpcx_group *group;           // MPCX_DEVICES=a,b,..: the element-wise protocols spread over these GPUs (else NULL)
 
     // ---- input / output (SecurennEngine.cpp:318-502)
     void share(const Words &plain, Words &mine);

@@ -114,6 +114,20 @@ template <class T> class Dev {
     operator const T *() const { return p; }
 };
 
+// bytes [byte_off, byte_off + bytes) of a message into the buffer from item dev_first on
+template <class T> inline void upload_string_at(Dev<T> &d, size_t dev_first, const std::string &s, size_t byte_off, size_t bytes) {
+    if (byte_off > s.size() || bytes > s.size() - byte_off) {
+        fprintf(stderr, "upload_string_at: bytes [%zu, +%zu) outside a message of %zu bytes\n", byte_off, bytes, s.size());
+        abort();
+    }
+    if (dev_first > d.n || bytes > (d.n - dev_first) * sizeof(T)) {
+        fprintf(stderr, "upload_string_at: %zu bytes from item %zu do not fit a device buffer of %zu items\n", bytes, dev_first,
+                d.n);
+        abort();
+    }
+    if (bytes) GPU_OK(d.ctx, mpcx_h2d(d.ctx, d.p + dev_first, s.data() + byte_off, bytes));
+}
+
 template <class T> inline void upload_string(Dev<T> &d, const std::string &s, size_t byte_off = 0, size_t bytes = (size_t)-1) {
     if (byte_off > s.size() || (bytes != (size_t)-1 && bytes > s.size() - byte_off)) {
         fprintf(stderr, "upload_string: bytes [%zu, +%zu) outside a message of %zu bytes\n", byte_off, bytes, s.size());
