@@ -2,7 +2,15 @@
 
 #include "gpu_support.hpp"
 
+using mpcgpu::Bufs;
 using mpcgpu::Dev;
+using mpcgpu::fresh;
+using mpcgpu::gather;
+using mpcgpu::get;
+using mpcgpu::members;
+using mpcgpu::put;
+using mpcgpu::run;
+using mpcgpu::scatter;
 using mpcgpu::upload_string;
 
 namespace {
@@ -17,10 +25,16 @@ MyEngine::MyEngine(VirtuleMessenger *_messenger, size_t _party_id) : messenger(_
     static const uint64_t pair_key[3][3] = {{KEY0, KEY01, KEY20}, {KEY01, KEY1, KEY12}, {KEY20, KEY12, KEY2}};
     assert(party_id < 3);
     for (size_t k = 0; k < 3; k++) prgs.push_back(PRgenerator(pair_key[party_id][k], 0));
-    gpu = mpcgpu::open_context();
+    group = mpcgpu::open_group();
+    gpu = group ? mpcx_group_ctx(group, 0) : mpcgpu::open_context();
 }
 
-MyEngine::~MyEngine() { mpcx_shutdown(gpu); }
+MyEngine::~MyEngine() {
+    if (group)
+        mpcx_group_shutdown(group);
+    else
+        mpcx_shutdown(gpu);
+}
 
 // ---- additive sharing between parties 0 and 1 out of their common stream; no communication
 void MyEngine::share(const VecI64 &X_plain, VecI64 &Xj) {
@@ -227,33 +241,45 @@ void MyEngine::vector_mul(const VecI64 &Xj, const VecI64 &Yj, VecI64 &Zj) {
         for (size_t i = 0; i < (size_t)zd.size(); i++) assert((uint64_t)zd[i] == (uint64_t)xd[i] * (uint64_t)yd[i]);
     });
 #endif
-    const size_t n = Xj.size();
+    // Like the protocols below, written over element ranges (mpcgpu::run): the engine's GPU takes the whole vector, the
+    // members of an MPCX_DEVICES group one contiguous range each, with their own slices of every message section.
+    const size_t n = Xj.size(), G = members(*this);
     assert((size_t)Yj.size() == n);
     Zj.resize(n);
     if (party_id == 2) {
-        Dev<int64_t> c0(gpu, n), c1(gpu, n);
-        GPU_OK(gpu, mpcx_my_beaver_dealer_vecmul(gpu, prgs[0].init_seed, prgs[1].init_seed, prgs[2].init_seed, n, 0, n, c0,
-                                                 c1));
-        c0.to_string(message_send[0]);
-        c1.to_string(message_send[1]);
+        for (size_t j = 0; j < 2; j++) message_send[j].resize(n * W);
+        run(*this, n, [&](mpcx_ctx *ctx, int, uint64_t i0, uint64_t cnt) {
+            Dev<int64_t> c0(ctx, cnt), c1(ctx, cnt);
+            GPU_OK(ctx, mpcx_my_beaver_dealer_vecmul(ctx, prgs[0].init_seed, prgs[1].init_seed, prgs[2].init_seed, n, i0, cnt,
+                                                     c0, c1));
+            put(c0, message_send[0], 0, i0, cnt);
+            put(c1, message_send[1], 0, i0, cnt);
+        });
         messenger->send_and_recv(message_send, message_recv);
         return;
     }
     const size_t peer = 1 - party_id;
     const uint64_t s2 = prgs[2].init_seed;
-    Dev<int64_t> ef(gpu, 2 * n), ef_peer(gpu, 2 * n), c(gpu, n), z(gpu, n);
-    {
-        Dev<int64_t> x(gpu, Xj.data(), n), y(gpu, Yj.data(), n);
-        GPU_OK(gpu, mpcx_my_beaver_party_open_vecmul(gpu, x, y, s2, n, 0, n, ef));
-    }
-    ef.to_string(message_send[peer]);
+    Bufs<int64_t> ef(G);
+    message_send[peer].resize(2 * n * W); // E | F
+    run(*this, n, [&](mpcx_ctx *ctx, int m, uint64_t i0, uint64_t cnt) {
+        Dev<int64_t> x(ctx, Xj.data() + i0, cnt), y(ctx, Yj.data() + i0, cnt);
+        Dev<int64_t> &efm = fresh(ef[m], ctx, 2 * cnt);
+        GPU_OK(ctx, mpcx_my_beaver_party_open_vecmul(ctx, x, y, s2, n, i0, cnt, efm));
+        put(efm, message_send[peer], 0, i0, cnt, 1, 0);
+        put(efm, message_send[peer], n * W, i0, cnt, 1, cnt);
+    });
     message_send[2].clear();
     messenger->send_and_recv(message_send, message_recv);
     MSG_CHECK(message_recv[2].size() == n * W && message_recv[peer].size() == 2 * n * W);
-    upload_string(c, message_recv[2]);
-    upload_string(ef_peer, message_recv[peer]);
-    GPU_OK(gpu, mpcx_my_beaver_party_finish_vecmul(gpu, (int)party_id, s2, c, ef, ef_peer, n, 0, n, z));
-    z.down(Zj.data(), n);
+    run(*this, n, [&](mpcx_ctx *ctx, int m, uint64_t i0, uint64_t cnt) {
+        Dev<int64_t> c(ctx, cnt), efp(ctx, 2 * cnt), z(ctx, cnt);
+        get(c, message_recv[2], 0, i0, cnt);
+        get(efp, message_recv[peer], 0, i0, cnt, 1, 0);
+        get(efp, message_recv[peer], n * W, i0, cnt, 1, cnt);
+        GPU_OK(ctx, mpcx_my_beaver_party_finish_vecmul(ctx, (int)party_id, s2, c, ef[m]->p, efp, n, i0, cnt, z));
+        if (cnt) z.down(Zj.data() + i0, cnt);
+    });
 }
 
 // ---- privateCompare: parties 0/1 send masked difference digits to party 2, which learns beta' = beta xor (x > r)
@@ -263,12 +289,15 @@ void MyEngine::privateCompare(const vector<zpshare> &Xbits_j, const vecbool &Bet
     assert(Beta1_plain.size() == n && (size_t)R_palin.size() == n);
     Beta2_plain.resize(n);
     if (party_id != 2) {
-        Dev<uint16_t> xb(gpu, (const uint16_t *)Xbits_j.data(), 64 * n), d(gpu, 64 * n);
-        Dev<int8_t> beta(gpu, Beta1_plain.data(), n);
-        Dev<int64_t> r(gpu, R_palin.data(), n);
-        GPU_OK(gpu, mpcx_my_pc_party(gpu, (int)party_id, xb, beta, r, 0, n, prgs[1 - party_id].init_seed, d));
         message_send[1 - party_id].clear();
-        d.to_string(message_send[2]);
+        message_send[2].resize(n * ZP);
+        run(*this, n, [&](mpcx_ctx *ctx, int, uint64_t i0, uint64_t cnt) {
+            Dev<uint16_t> xb(ctx, (const uint16_t *)Xbits_j.data() + 64 * i0, 64 * cnt), d(ctx, 64 * cnt);
+            Dev<int8_t> beta(ctx, Beta1_plain.data() + i0, cnt);
+            Dev<int64_t> r(ctx, R_palin.data() + i0, cnt);
+            GPU_OK(ctx, mpcx_my_pc_party(ctx, (int)party_id, xb, beta, r, i0, cnt, prgs[1 - party_id].init_seed, d));
+            put(d, message_send[2], 0, i0, cnt, 64);
+        });
         messenger->send_and_recv(message_send, message_recv);
         return;
     }
@@ -276,12 +305,14 @@ void MyEngine::privateCompare(const vector<zpshare> &Xbits_j, const vecbool &Bet
     message_send[1].clear();
     messenger->send_and_recv(message_send, message_recv);
     MSG_CHECK(message_recv[0].size() == n * ZP && message_recv[1].size() == n * ZP);
-    Dev<uint16_t> d0(gpu, 64 * n), d1(gpu, 64 * n);
-    Dev<int8_t> b(gpu, n);
-    upload_string(d0, message_recv[0]);
-    upload_string(d1, message_recv[1]);
-    GPU_OK(gpu, mpcx_snn_pc_helper(gpu, d0, d1, n, b));
-    b.down(Beta2_plain.data(), n);
+    run(*this, n, [&](mpcx_ctx *ctx, int, uint64_t i0, uint64_t cnt) {
+        Dev<uint16_t> d0(ctx, 64 * cnt), d1(ctx, 64 * cnt);
+        Dev<int8_t> b(ctx, cnt);
+        get(d0, message_recv[0], 0, i0, cnt, 64);
+        get(d1, message_recv[1], 0, i0, cnt, 64);
+        GPU_OK(ctx, mpcx_snn_pc_helper(ctx, d0, d1, cnt, b));
+        if (cnt) b.down(Beta2_plain.data() + i0, cnt);
+    });
 }
 
 // ---- msb of a in [-2^62, 2^62): three rounds, XOR-shared result
@@ -295,66 +326,76 @@ void MyEngine::msb(const VecI64 &Aj, vecbool &Bj) {
         for (size_t i = 0; i < bd.size(); i++) assert(bd[i] == (int8_t)(ad[i] < 0));
     });
 #endif
-    const size_t n = Aj.size();
+    const size_t n = Aj.size(), G = members(*this);
     Bj.assign(n, 0);
     if (party_id == 2) {
         const uint64_t s0 = prgs[0].init_seed, s1 = prgs[1].init_seed, sS = prgs[2].init_seed;
-        {
-            Dev<int8_t> l0(gpu, n), l1(gpu, n);
-            Dev<uint16_t> xb0(gpu, 64 * n), xb1(gpu, 64 * n);
-            GPU_OK(gpu, mpcx_my_msb_helper_deal(gpu, s0, s1, sS, 0, n, l0, xb0, l1, xb1));
-            for (size_t j = 0; j < 2; j++) { // lsb share | bit shares (:502-508)
-                message_send[j].resize(n + n * ZP);
-                if (n) {
-                    (j ? l1 : l0).down(&message_send[j][0], n);
-                    (j ? xb1 : xb0).down(&message_send[j][n], 64 * n);
-                }
-            }
-        }
+        for (size_t j = 0; j < 2; j++) message_send[j].resize(n + n * ZP); // lsb share | bit shares (:502-508)
+        run(*this, n, [&](mpcx_ctx *ctx, int, uint64_t i0, uint64_t cnt) {
+            Dev<int8_t> l0(ctx, cnt), l1(ctx, cnt);
+            Dev<uint16_t> xb0(ctx, 64 * cnt), xb1(ctx, 64 * cnt);
+            GPU_OK(ctx, mpcx_my_msb_helper_deal(ctx, s0, s1, sS, i0, cnt, l0, xb0, l1, xb1));
+            put(l0, message_send[0], 0, i0, cnt);
+            put(xb0, message_send[0], n, i0, cnt, 64);
+            put(l1, message_send[1], 0, i0, cnt);
+            put(xb1, message_send[1], n, i0, cnt, 64);
+        });
         messenger->send_and_recv(message_send, message_recv); // round 1
         message_send[0].clear();
         message_send[1].clear();
         messenger->send_and_recv(message_send, message_recv); // round 2: privateCompare as the helper
         MSG_CHECK(message_recv[0].size() == n * ZP && message_recv[1].size() == n * ZP);
-        Dev<uint16_t> d0(gpu, 64 * n), d1(gpu, 64 * n);
-        Dev<int8_t> beta1(gpu, n), b0(gpu, n), b1(gpu, n);
-        upload_string(d0, message_recv[0]);
-        upload_string(d1, message_recv[1]);
-        GPU_OK(gpu, mpcx_snn_pc_helper(gpu, d0, d1, n, beta1));
-        GPU_OK(gpu, mpcx_my_msb_helper_beta(gpu, beta1, n, 0, n, sS, b0, b1));
-        b0.to_string(message_send[0]);
-        b1.to_string(message_send[1]);
+        for (size_t j = 0; j < 2; j++) message_send[j].resize(n);
+        run(*this, n, [&](mpcx_ctx *ctx, int, uint64_t i0, uint64_t cnt) {
+            Dev<uint16_t> d0(ctx, 64 * cnt), d1(ctx, 64 * cnt);
+            Dev<int8_t> beta1(ctx, cnt), b0(ctx, cnt), b1(ctx, cnt);
+            get(d0, message_recv[0], 0, i0, cnt, 64);
+            get(d1, message_recv[1], 0, i0, cnt, 64);
+            GPU_OK(ctx, mpcx_snn_pc_helper(ctx, d0, d1, cnt, beta1));
+            GPU_OK(ctx, mpcx_my_msb_helper_beta(ctx, beta1, n, i0, cnt, sS, b0, b1));
+            put(b0, message_send[0], 0, i0, cnt);
+            put(b1, message_send[1], 0, i0, cnt);
+        });
         messenger->send_and_recv(message_send, message_recv); // round 3
         return;
     }
     const size_t peer = 1 - party_id;
     const uint64_t s01 = prgs[peer].init_seed, s2 = prgs[2].init_seed;
-    Dev<int64_t> rj(gpu, n), rpeer(gpu, n), R(gpu, n);
-    {
-        Dev<int64_t> a(gpu, Aj.data(), n);
-        GPU_OK(gpu, mpcx_my_msb_party_open(gpu, a, s2, 0, n, rj));
-    }
+    Bufs<int64_t> rj(G), R(G);
+    Bufs<int8_t> beta0(G), xlsb(G);
     message_send[2].clear();
-    rj.to_string(message_send[peer]);
+    message_send[peer].resize(n * W);
+    run(*this, n, [&](mpcx_ctx *ctx, int m, uint64_t i0, uint64_t cnt) {
+        Dev<int64_t> a(ctx, Aj.data() + i0, cnt);
+        GPU_OK(ctx, mpcx_my_msb_party_open(ctx, a, s2, i0, cnt, fresh(rj[m], ctx, cnt)));
+        put(*rj[m], message_send[peer], 0, i0, cnt);
+    });
     messenger->send_and_recv(message_send, message_recv); // round 1
     MSG_CHECK(message_recv[peer].size() == n * W && message_recv[2].size() == n + n * ZP);
-    upload_string(rpeer, message_recv[peer]);
-    Dev<int8_t> beta0(gpu, n), xlsb(gpu, n), beta1(gpu, n), out(gpu, n);
-    Dev<uint16_t> xbits(gpu, 64 * n), d(gpu, 64 * n);
-    upload_string(xlsb, message_recv[2], 0, n);
-    upload_string(xbits, message_recv[2], n, n * ZP);
-    GPU_OK(gpu, mpcx_my_msb_party_pc_inputs(gpu, rj, rpeer, 0, n, s01, beta0, R));
-    GPU_OK(gpu, mpcx_my_pc_party(gpu, (int)party_id, xbits, beta0, R, 0, n, s01, d));
     message_send[peer].clear();
-    d.to_string(message_send[2]);
+    message_send[2].resize(n * ZP);
+    run(*this, n, [&](mpcx_ctx *ctx, int m, uint64_t i0, uint64_t cnt) {
+        Dev<int64_t> rpeer(ctx, cnt);
+        Dev<uint16_t> xbits(ctx, 64 * cnt), d(ctx, 64 * cnt);
+        get(rpeer, message_recv[peer], 0, i0, cnt);
+        get(fresh(xlsb[m], ctx, cnt), message_recv[2], 0, i0, cnt);
+        get(xbits, message_recv[2], n, i0, cnt, 64);
+        GPU_OK(ctx, mpcx_my_msb_party_pc_inputs(ctx, rj[m]->p, rpeer, i0, cnt, s01, fresh(beta0[m], ctx, cnt),
+                                                fresh(R[m], ctx, cnt)));
+        GPU_OK(ctx, mpcx_my_pc_party(ctx, (int)party_id, xbits, beta0[m]->p, R[m]->p, i0, cnt, s01, d));
+        put(d, message_send[2], 0, i0, cnt, 64);
+    });
     messenger->send_and_recv(message_send, message_recv); // round 2
     message_send[2].clear();
     message_send[peer].clear();
     messenger->send_and_recv(message_send, message_recv); // round 3: share of beta'
     MSG_CHECK(message_recv[2].size() == n);
-    upload_string(beta1, message_recv[2]);
-    GPU_OK(gpu, mpcx_my_msb_party_finish(gpu, (int)party_id, beta1, beta0, xlsb, R, n, out));
-    out.down(Bj.data(), n);
+    run(*this, n, [&](mpcx_ctx *ctx, int m, uint64_t i0, uint64_t cnt) {
+        Dev<int8_t> beta1(ctx, cnt), out(ctx, cnt);
+        get(beta1, message_recv[2], 0, i0, cnt);
+        GPU_OK(ctx, mpcx_my_msb_party_finish(ctx, (int)party_id, beta1, beta0[m]->p, xlsb[m]->p, R[m]->p, cnt, out));
+        if (cnt) out.down(Bj.data() + i0, cnt);
+    });
 }
 
 // ---- x * a for an XOR-shared boolean a, one round
@@ -369,40 +410,47 @@ void MyEngine::bit_inject(const VecI64 &Xj, const vecbool &Aj, VecI64 &Zj) {
         for (size_t i = 0; i < (size_t)zd.size(); i++) assert(zd[i] == (ad[i] ? xd[i] : 0));
     });
 #endif
-    const size_t n = Xj.size();
+    const size_t n = Xj.size(), G = members(*this);
     assert(Aj.size() == n);
     Zj.resize(n);
     if (party_id == 2) {
-        Dev<int64_t> m0(gpu, 4 * n), m1(gpu, 4 * n); // V | W | S | T
-        GPU_OK(gpu, mpcx_my_bit_inject_dealer(gpu, prgs[0].init_seed, prgs[1].init_seed, prgs[2].init_seed, n, 0, n, m0.p,
-                                              m0.p + n, m0.p + 2 * n, m0.p + 3 * n, m1.p, m1.p + n, m1.p + 2 * n,
-                                              m1.p + 3 * n));
-        m0.to_string(message_send[0]);
-        m1.to_string(message_send[1]);
+        for (size_t j = 0; j < 2; j++) message_send[j].resize(4 * n * W); // V | W | S | T
+        run(*this, n, [&](mpcx_ctx *ctx, int, uint64_t i0, uint64_t cnt) {
+            Dev<int64_t> m0(ctx, 4 * cnt), m1(ctx, 4 * cnt);
+            GPU_OK(ctx, mpcx_my_bit_inject_dealer(ctx, prgs[0].init_seed, prgs[1].init_seed, prgs[2].init_seed, n, i0, cnt, m0.p,
+                                                  m0.p + cnt, m0.p + 2 * cnt, m0.p + 3 * cnt, m1.p, m1.p + cnt,
+                                                  m1.p + 2 * cnt, m1.p + 3 * cnt));
+            for (size_t k = 0; k < 4; k++) {
+                put(m0, message_send[0], k * n * W, i0, cnt, 1, k * cnt);
+                put(m1, message_send[1], k * n * W, i0, cnt, 1, k * cnt);
+            }
+        });
         messenger->send_and_recv(message_send, message_recv);
         return;
     }
     const size_t peer = 1 - party_id;
     const uint64_t s2 = prgs[2].init_seed;
-    Dev<int64_t> y(gpu, n), ypeer(gpu, n), deal(gpu, 4 * n), z(gpu, n);
-    Dev<int8_t> c(gpu, n), cpeer(gpu, n);
-    {
-        Dev<int64_t> x(gpu, Xj.data(), n);
-        Dev<int8_t> a(gpu, Aj.data(), n);
-        GPU_OK(gpu, mpcx_my_bit_inject_party_pre(gpu, x, a, s2, 0, n, y, c));
-    }
+    Bufs<int64_t> y(G);
+    Bufs<int8_t> c(G);
     message_send[peer].resize(n * W + n); // y | c (:621-623)
-    if (n) {
-        y.down(&message_send[peer][0], n);
-        c.down(&message_send[peer][n * W], n);
-    }
+    run(*this, n, [&](mpcx_ctx *ctx, int m, uint64_t i0, uint64_t cnt) {
+        Dev<int64_t> x(ctx, Xj.data() + i0, cnt);
+        Dev<int8_t> a(ctx, Aj.data() + i0, cnt);
+        GPU_OK(ctx, mpcx_my_bit_inject_party_pre(ctx, x, a, s2, i0, cnt, fresh(y[m], ctx, cnt), fresh(c[m], ctx, cnt)));
+        put(*y[m], message_send[peer], 0, i0, cnt);
+        put(*c[m], message_send[peer], n * W, i0, cnt);
+    });
     message_send[2].clear();
     messenger->send_and_recv(message_send, message_recv);
     MSG_CHECK(message_recv[peer].size() == n * W + n && message_recv[2].size() == 4 * n * W);
-    upload_string(ypeer, message_recv[peer], 0, n * W);
-    upload_string(cpeer, message_recv[peer], n * W, n);
-    upload_string(deal, message_recv[2]);
-    GPU_OK(gpu, mpcx_my_bit_inject_party_post(gpu, (int)party_id, s2, 0, n, y, c, ypeer, cpeer, deal.p, deal.p + n,
-                                              deal.p + 2 * n, deal.p + 3 * n, z));
-    z.down(Zj.data(), n);
+    run(*this, n, [&](mpcx_ctx *ctx, int m, uint64_t i0, uint64_t cnt) {
+        Dev<int64_t> ypeer(ctx, cnt), deal(ctx, 4 * cnt), z(ctx, cnt);
+        Dev<int8_t> cpeer(ctx, cnt);
+        get(ypeer, message_recv[peer], 0, i0, cnt);
+        get(cpeer, message_recv[peer], n * W, i0, cnt);
+        for (size_t k = 0; k < 4; k++) get(deal, message_recv[2], k * n * W, i0, cnt, 1, k * cnt);
+        GPU_OK(ctx, mpcx_my_bit_inject_party_post(ctx, (int)party_id, s2, i0, cnt, y[m]->p, c[m]->p, ypeer, cpeer, deal.p,
+                                                  deal.p + cnt, deal.p + 2 * cnt, deal.p + 3 * cnt, z));
+        if (cnt) z.down(Zj.data() + i0, cnt);
+    });
 }

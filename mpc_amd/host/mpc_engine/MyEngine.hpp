@@ -30,6 +30,7 @@ using std::string;
 using std::vector;
 
 struct mpcx_ctx;
+struct mpcx_group;
 
 class MyEngine {
   public:
@@ -44,6 +45,7 @@ class MyEngine {
     vector<string> message_send;
     vector<string> message_recv;
     mpcx_ctx *gpu;               // this engine's GPU context (an addition)
+    mpcx_group *group;           // MPCX_DEVICES=a,b,..: the element-wise protocols spread over these GPUs (else NULL)
 
     // ---- input / output (MyEngine.cpp:54-143, :777-end)
     void share(const VecI64 &plain, VecI64 &mine);

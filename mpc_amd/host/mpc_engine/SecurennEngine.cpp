@@ -5,9 +5,17 @@
 #include "../utils/util.hpp"
 #include "gpu_support.hpp"
 
+using mpcgpu::Buf;
+using mpcgpu::Bufs;
 using mpcgpu::Dev;
+using mpcgpu::fresh;
+using mpcgpu::gather;
+using mpcgpu::get;
+using mpcgpu::members;
+using mpcgpu::put;
+using mpcgpu::run;
+using mpcgpu::scatter;
 using mpcgpu::upload_string;
-using mpcgpu::upload_string_at;
 
 namespace {
 const size_t W = sizeof(int64_t);
@@ -243,32 +251,6 @@ void SecurennEngine::reveal_zp(const vector<zpshare> &Xbits_j, vector<zpshare> &
 // concatenation of sections (one per array it carries), each section holding the elements in order.
 namespace {
 
-const uint64_t RANGE_GRANULE = 64;
-template <class T> using Buf = std::unique_ptr<Dev<T>>;
-template <class T> using Bufs = vector<Buf<T>>;
-
-template <class F> void run(SecurennEngine &e, size_t n, F f) {
-    if (e.group && n)
-        mpcgpu::group_for_each(e.group, n, RANGE_GRANULE, f);
-    else
-        f(e.gpu, 0, (uint64_t)0, (uint64_t)n);
-}
-size_t members(const SecurennEngine &e) { return e.group ? (size_t)mpcx_group_size(e.group) : 1; }
-template <class T> Dev<T> &fresh(Buf<T> &b, mpcx_ctx *ctx, size_t count) {
-    b.reset(new Dev<T>(ctx, count));
-    return *b;
-}
-// `count` elements of `per` items each, from item dev_first of the buffer, into / out of the section that starts at
-// byte `section` of the message, at element `first`
-template <class T>
-void put(const Dev<T> &d, string &msg, size_t section, size_t first, size_t count, size_t per = 1, size_t dev_first = 0) {
-    if (count) d.down(&msg[section + first * per * sizeof(T)], count * per, dev_first);
-}
-template <class T>
-void get(Dev<T> &d, const string &msg, size_t section, size_t first, size_t count, size_t per = 1, size_t dev_first = 0) {
-    upload_string_at(d, dev_first, msg, section + first * per * sizeof(T), count * per * sizeof(T));
-}
-
 struct PcIn { // what a party brings to privateCompare, per member
     Bufs<uint16_t> xbits;
     Bufs<int8_t> beta;
@@ -489,16 +471,6 @@ void msb_L1_dev(SecurennEngine &e, const Bufs<int64_t> *a, size_t n, Bufs<int64_
     vecmul_party_dev(e, gamma, delta, n, theta); // rounds 5-6
     run(e, n, [&](mpcx_ctx *ctx, int m, uint64_t, uint64_t cnt) {
         GPU_OK(ctx, mpcx_snn_msbl1_party_finish(ctx, gamma[m]->p, delta[m]->p, theta[m]->p, cnt, fresh((*b)[m], ctx, cnt)));
-    });
-}
-
-// host vector -> one device buffer per member, and back
-template <class T> void scatter(SecurennEngine &e, const T *host, size_t n, size_t per, Bufs<T> &d) {
-    run(e, n, [&](mpcx_ctx *ctx, int m, uint64_t i0, uint64_t cnt) { fresh(d[m], ctx, per * cnt).up(host + per * i0, per * cnt); });
-}
-template <class T> void gather(SecurennEngine &e, const Bufs<T> &d, size_t n, T *host) {
-    run(e, n, [&](mpcx_ctx *, int m, uint64_t i0, uint64_t cnt) {
-        if (cnt) d[m]->down(host + i0, cnt);
     });
 }
 

@@ -5,6 +5,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -139,6 +140,49 @@ template <class T> inline void upload_string(Dev<T> &d, const std::string &s, si
         abort();
     }
     if (bytes) GPU_OK(d.ctx, mpcx_h2d(d.ctx, d.p, s.data() + byte_off, bytes));
+}
+
+// ---- protocols written over element ranges.  An engine E has a context `gpu` and a group `group` (NULL without
+// MPCX_DEVICES).  run() hands the whole vector to the engine's one GPU, or every member of the group its own contiguous
+// range [first, first + count) on the member's thread.  A member keeps its device buffers across the rounds (one slot
+// per member in a Bufs), runs the range forms of the library's segments and moves its own slices of the messages: a
+// message is the concatenation of sections (one per array it carries), each section holding the elements in order.
+const uint64_t RANGE_GRANULE = 64;
+template <class T> using Buf = std::unique_ptr<Dev<T>>;
+template <class T> using Bufs = std::vector<Buf<T>>;
+
+// f(ctx, member, first, count)
+template <class E, class F> inline void run(E &e, size_t n, F f) {
+    if (e.group && n)
+        group_for_each(e.group, n, RANGE_GRANULE, f);
+    else
+        f(e.gpu, 0, (uint64_t)0, (uint64_t)n);
+}
+template <class E> inline size_t members(const E &e) { return e.group ? (size_t)mpcx_group_size(e.group) : 1; }
+template <class T> inline Dev<T> &fresh(Buf<T> &b, mpcx_ctx *ctx, size_t count) {
+    b.reset(new Dev<T>(ctx, count));
+    return *b;
+}
+// `count` elements of `per` items each, from item dev_first of the buffer, into / out of the section that starts at
+// byte `section` of the message, at element `first`
+template <class T>
+inline void put(const Dev<T> &d, std::string &msg, size_t section, size_t first, size_t count, size_t per = 1,
+                size_t dev_first = 0) {
+    if (count) d.down(&msg[section + first * per * sizeof(T)], count * per, dev_first);
+}
+template <class T>
+inline void get(Dev<T> &d, const std::string &msg, size_t section, size_t first, size_t count, size_t per = 1,
+                size_t dev_first = 0) {
+    upload_string_at(d, dev_first, msg, section + first * per * sizeof(T), count * per * sizeof(T));
+}
+// host vector -> one device buffer per member, and back
+template <class E, class T> inline void scatter(E &e, const T *host, size_t n, size_t per, Bufs<T> &d) {
+    run(e, n, [&](mpcx_ctx *ctx, int m, uint64_t i0, uint64_t cnt) { fresh(d[m], ctx, per * cnt).up(host + per * i0, per * cnt); });
+}
+template <class E, class T> inline void gather(E &e, const Bufs<T> &d, size_t n, T *host) {
+    run(e, n, [&](mpcx_ctx *, int m, uint64_t i0, uint64_t cnt) {
+        if (cnt) d[m]->down(host + i0, cnt);
+    });
 }
 
 } // namespace mpcgpu

@@ -86,8 +86,8 @@ def kat_lines(env):
 
 def test_host_engines_over_a_group_give_the_same_shares():
     """The C++ engines' own test program with MPCX_DEVICES=0,0 (ABY3 matrix_mul in row blocks, add_prepare / msb /
-    bit_inject in element ranges; SecurennEngine vector_mul / privateCompare / shareConvert / msb_L_1 / msb in element
-    ranges over two and three contexts): every assertion holds and every share checksum is the one of the
+    bit_inject in element ranges; SecurennEngine vector_mul / privateCompare / shareConvert / msb_L_1 / msb and MyEngine
+    vector_mul / privateCompare / msb / bit_inject in element ranges over two and three contexts): every assertion holds and every share checksum is the one of the
     single-context run."""
     one = kat_lines({"MPCX_DEVICES": ""})
     two = kat_lines({"MPCX_DEVICES": "0,0"})
@@ -105,12 +105,13 @@ def test_host_benchmark_over_a_group_verifies():
     assert r.returncode == 0 and "all results verified" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
 
 
-def test_host_securenn_benchmark_over_a_group_verifies():
-    """benchmark1's SecureNN lines (msb + vector_mul on 100 000 elements in ranges over three contexts, matrix_mul on
-    the first): the program checks every result against the plain computation."""
+@pytest.mark.parametrize("engine", ["securenn", "my"])
+def test_host_additive_engines_benchmark_over_a_group_verifies(engine):
+    """benchmark1's SecureNN / MyEngine lines (msb + vector_mul / bit_inject on 100 000 elements in ranges over three
+    contexts, matrix_mul on the first): the program checks every result against the plain computation."""
     exe = os.path.join(HOST, "benchmark1")
     assert os.path.exists(exe), "mpc_amd/host/benchmark1 missing: run __graft_entry__.build()"
-    r = subprocess.run([exe, "--engine", "securenn", "--width", "256", "--vec", "100000", "--repeat", "1", "--no-mlp"],
+    r = subprocess.run([exe, "--engine", engine, "--width", "256", "--vec", "100000", "--repeat", "1", "--no-mlp"],
                        capture_output=True, text=True, timeout=600, env=dict(os.environ, MPCX_DEVICES="0,0,0"))
     assert r.returncode == 0 and "all results verified" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
 
