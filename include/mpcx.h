@@ -64,6 +64,9 @@ int mpcx_host_copy(void *dst, const void *src, uint64_t bytes);
  * family since then: "limb_gemm", "split_limbs", "prg_fill", "pc_party", "pc_helper",
  * "msb_round" */
 int mpcx_profile(mpcx_ctx *ctx, int enable);
+/* restricts the collection to one kernel family (NULL: all again).  Every recorded event costs the stream a few
+ * microseconds between two kernels, so a timed region that needs one kernel's durations asks for that one only. */
+int mpcx_profile_select(mpcx_ctx *ctx, const char *kernel);
 int mpcx_profile_read(mpcx_ctx *ctx, const char *kernel, double *total_ms, uint64_t *launches);
 /* grows the context's scratch workspace up front so that later calls do not allocate */
 int mpcx_reserve_workspace(mpcx_ctx *ctx, uint64_t bytes);

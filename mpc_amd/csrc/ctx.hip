@@ -379,6 +379,19 @@ int mpcx_profile(mpcx_ctx *ctx, int enable) {
     ctx->prof = enable != 0;
     return 0;
 }
+int mpcx_profile_select(mpcx_ctx *ctx, const char *kernel) {
+    MPCX_REQUIRE(ctx, "mpcx_profile_select: the context is NULL (already shut down?)");
+    if (!kernel) {
+        ctx->prof_mask = ~0u;
+        return 0;
+    }
+    for (int s = 0; s < PROF_SLOTS; s++)
+        if (std::string(kernel) == kProfNames[s]) {
+            ctx->prof_mask = 1u << s;
+            return 0;
+        }
+    return mpcx_fail(ctx, "mpcx_profile_select: unknown kernel name '%s'", kernel);
+}
 int mpcx_profile_read(mpcx_ctx *ctx, const char *kernel, double *total_ms, uint64_t *launches) {
     MPCX_REQUIRE(ctx, "mpcx_profile_read: the context is NULL (already shut down?)");
     MPCX_REQUIRE(kernel && total_ms && launches, "mpcx_profile_read: NULL pointer");

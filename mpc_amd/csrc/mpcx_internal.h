@@ -36,6 +36,7 @@ enum ProfSlotId { PROF_GEMM = 0, PROF_SPLIT, PROF_PRG, PROF_PC_PARTY, PROF_PC_HE
 
 struct mpcx_ctx {
     bool prof = false;
+    unsigned prof_mask = ~0u; // slots that record (mpcx_profile_select)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev[PROF_SLOTS];
     int device = 0;
     hipStream_t stream = nullptr;
@@ -95,7 +96,7 @@ struct ProfScope {
     int slot;
     hipEvent_t stop = nullptr;
     ProfScope(mpcx_ctx *c, int s) : ctx(c), slot(s) {
-        if (!ctx->prof) return;
+        if (!ctx->prof || !((ctx->prof_mask >> s) & 1u)) return;
         hipEvent_t start;
         if (hipEventCreate(&start) != hipSuccess || hipEventCreate(&stop) != hipSuccess) {
             stop = nullptr;
