@@ -325,3 +325,39 @@ def test_aby3_msb_messages_at_8_byte_alignment(gpu, orc, n, monkeypatch):
     for j in range(3):
         for i in range(2):
             assert np.array_equal(res[0][1][j][i], res[1][1][j][i])
+
+
+def test_profile_collects_per_family_and_select_restricts_it(gpu):
+    """mpcx_profile / mpcx_profile_select / mpcx_profile_read: launches are counted per kernel family, a selected
+    family is the only one that records, and the kernel-name query names the GEMM kernel a shape runs in."""
+    import ctypes
+    from mpc_amd import MpcxError, load_library
+    ctx = gpu.ctx
+    rng = np.random.default_rng(3)
+    r, l, c = 130, 70, 66
+    A, B = ctx.to_device(rnd(rng, r * l)), ctx.to_device(rnd(rng, l * c))
+    Z = ctx.to_device(np.zeros(r * c, np.int64))
+
+    def read(name):
+        ms, cnt = ctypes.c_double(), ctypes.c_uint64()
+        ctx._call("mpcx_profile_read", name.encode(), ctypes.byref(ms), ctypes.byref(cnt))
+        return ms.value, cnt.value
+
+    ctx.call("profile", 1)
+    for _ in range(2):
+        ctx.call("ring_gemm_u64", A, B, Z, r, l, c, 0, 0, 0, 0)
+    ms, cnt = read("limb_gemm")
+    assert cnt == 2 and ms > 0 and read("split_limbs")[1] >= 2
+    ctx._call("mpcx_profile_select", b"limb_gemm")
+    ctx.call("profile", 1)  # clears
+    ctx.call("ring_gemm_u64", A, B, Z, r, l, c, 0, 0, 0, 0)
+    assert read("limb_gemm")[1] == 1 and read("split_limbs")[1] == 0
+    with pytest.raises(MpcxError, match="unknown kernel name"):
+        ctx._call("mpcx_profile_select", b"no_such_kernel")
+    ctx._call("mpcx_profile_select", None)
+    ctx.call("profile", 0)
+    name = load_library().mpcx_ring_gemm_kernel_name
+    name.restype = ctypes.c_char_p
+    U = ctypes.c_uint64
+    assert name(U(r), U(l), U(c)) == b"limb_gemm_kernel"
+    assert name(U(4096), U(8192), U(4096)) in (b"rns_gemm_wide_kernel", b"rns_gemm_kernel")
