@@ -7,8 +7,10 @@ using mpcgpu::Dev;
 using mpcgpu::fresh;
 using mpcgpu::gather;
 using mpcgpu::get;
+using mpcgpu::get_sections;
 using mpcgpu::members;
 using mpcgpu::put;
+using mpcgpu::put_sections;
 using mpcgpu::run;
 using mpcgpu::scatter;
 using mpcgpu::upload_string;
@@ -266,8 +268,7 @@ void MyEngine::vector_mul(const VecI64 &Xj, const VecI64 &Yj, VecI64 &Zj) {
         Dev<int64_t> x(ctx, Xj.data() + i0, cnt), y(ctx, Yj.data() + i0, cnt);
         Dev<int64_t> &efm = fresh(ef[m], ctx, 2 * cnt);
         GPU_OK(ctx, mpcx_my_beaver_party_open_vecmul(ctx, x, y, s2, n, i0, cnt, efm));
-        put(efm, message_send[peer], 0, i0, cnt, 1, 0);
-        put(efm, message_send[peer], n * W, i0, cnt, 1, cnt);
+        put_sections(efm, message_send[peer], 0, 2, n, i0, cnt);
     });
     message_send[2].clear();
     messenger->send_and_recv(message_send, message_recv);
@@ -275,8 +276,7 @@ void MyEngine::vector_mul(const VecI64 &Xj, const VecI64 &Yj, VecI64 &Zj) {
     run(*this, n, [&](mpcx_ctx *ctx, int m, uint64_t i0, uint64_t cnt) {
         Dev<int64_t> c(ctx, cnt), efp(ctx, 2 * cnt), z(ctx, cnt);
         get(c, message_recv[2], 0, i0, cnt);
-        get(efp, message_recv[peer], 0, i0, cnt, 1, 0);
-        get(efp, message_recv[peer], n * W, i0, cnt, 1, cnt);
+        get_sections(efp, message_recv[peer], 0, 2, n, i0, cnt);
         GPU_OK(ctx, mpcx_my_beaver_party_finish_vecmul(ctx, (int)party_id, s2, c, ef[m]->p, efp, n, i0, cnt, z));
         if (cnt) z.down(Zj.data() + i0, cnt);
     });
@@ -420,10 +420,8 @@ void MyEngine::bit_inject(const VecI64 &Xj, const vecbool &Aj, VecI64 &Zj) {
             GPU_OK(ctx, mpcx_my_bit_inject_dealer(ctx, prgs[0].init_seed, prgs[1].init_seed, prgs[2].init_seed, n, i0, cnt, m0.p,
                                                   m0.p + cnt, m0.p + 2 * cnt, m0.p + 3 * cnt, m1.p, m1.p + cnt,
                                                   m1.p + 2 * cnt, m1.p + 3 * cnt));
-            for (size_t k = 0; k < 4; k++) {
-                put(m0, message_send[0], k * n * W, i0, cnt, 1, k * cnt);
-                put(m1, message_send[1], k * n * W, i0, cnt, 1, k * cnt);
-            }
+            put_sections(m0, message_send[0], 0, 4, n, i0, cnt);
+            put_sections(m1, message_send[1], 0, 4, n, i0, cnt);
         });
         messenger->send_and_recv(message_send, message_recv);
         return;
@@ -448,7 +446,7 @@ void MyEngine::bit_inject(const VecI64 &Xj, const vecbool &Aj, VecI64 &Zj) {
         Dev<int8_t> cpeer(ctx, cnt);
         get(ypeer, message_recv[peer], 0, i0, cnt);
         get(cpeer, message_recv[peer], n * W, i0, cnt);
-        for (size_t k = 0; k < 4; k++) get(deal, message_recv[2], k * n * W, i0, cnt, 1, k * cnt);
+        get_sections(deal, message_recv[2], 0, 4, n, i0, cnt);
         GPU_OK(ctx, mpcx_my_bit_inject_party_post(ctx, (int)party_id, s2, i0, cnt, y[m]->p, c[m]->p, ypeer, cpeer, deal.p,
                                                   deal.p + cnt, deal.p + 2 * cnt, deal.p + 3 * cnt, z));
         if (cnt) z.down(Zj.data() + i0, cnt);

@@ -11,8 +11,10 @@ using mpcgpu::Dev;
 using mpcgpu::fresh;
 using mpcgpu::gather;
 using mpcgpu::get;
+using mpcgpu::get_sections;
 using mpcgpu::members;
 using mpcgpu::put;
+using mpcgpu::put_sections;
 using mpcgpu::run;
 using mpcgpu::scatter;
 using mpcgpu::upload_string;
@@ -291,10 +293,8 @@ void vecmul_dealer(SecurennEngine &e, size_t n) {
         Dev<int64_t> t0(ctx, 3 * cnt), t1(ctx, 3 * cnt);
         GPU_OK(ctx, mpcx_snn_beaver_dealer_vecmul(ctx, e.prgs[2].init_seed, n, i0, cnt, t0.p, t0.p + cnt, t0.p + 2 * cnt, t1.p,
                                                   t1.p + cnt, t1.p + 2 * cnt));
-        for (size_t k = 0; k < 3; k++) {
-            put(t0, e.message_send[0], k * n * W, i0, cnt, 1, k * cnt);
-            put(t1, e.message_send[1], k * n * W, i0, cnt, 1, k * cnt);
-        }
+        put_sections(t0, e.message_send[0], 0, 3, n, i0, cnt);
+        put_sections(t1, e.message_send[1], 0, 3, n, i0, cnt);
     });
     e.messenger->send_and_recv(e.message_send, e.message_recv); // round 1
     e.message_send[0].clear();
@@ -312,18 +312,16 @@ void vecmul_party_dev(SecurennEngine &e, const Bufs<int64_t> &x, const Bufs<int6
     out.resize(2 * n * W);
     run(e, n, [&](mpcx_ctx *ctx, int m, uint64_t i0, uint64_t cnt) {
         Dev<int64_t> &tm = fresh(t[m], ctx, 3 * cnt), &efm = fresh(ef[m], ctx, 2 * cnt);
-        for (size_t k = 0; k < 3; k++) get(tm, e.message_recv[2], k * n * W, i0, cnt, 1, k * cnt);
+        get_sections(tm, e.message_recv[2], 0, 3, n, i0, cnt);
         GPU_OK(ctx, mpcx_snn_beaver_party_open_vecmul(ctx, x[m]->p, y[m]->p, tm.p, tm.p + cnt, cnt, efm.p, efm.p + cnt));
-        put(efm, out, 0, i0, cnt, 1, 0);
-        put(efm, out, n * W, i0, cnt, 1, cnt);
+        put_sections(efm, out, 0, 2, n, i0, cnt);
     });
     e.message_send[2].clear();
     e.messenger->send_and_recv(e.message_send, e.message_recv); // round 2
     MSG_CHECK(e.message_recv[peer].size() == 2 * n * W);
     run(e, n, [&](mpcx_ctx *ctx, int m, uint64_t i0, uint64_t cnt) {
         Dev<int64_t> efp(ctx, 2 * cnt);
-        get(efp, e.message_recv[peer], 0, i0, cnt, 1, 0);
-        get(efp, e.message_recv[peer], n * W, i0, cnt, 1, cnt);
+        get_sections(efp, e.message_recv[peer], 0, 2, n, i0, cnt);
         Dev<int64_t> &tm = *t[m], &efm = *ef[m];
         GPU_OK(ctx, mpcx_snn_beaver_party_finish_vecmul(ctx, (int)e.party_id, tm.p, tm.p + cnt, tm.p + 2 * cnt, efm.p,
                                                         efm.p + cnt, efp.p, efp.p + cnt, cnt, fresh(z[m], ctx, cnt)));

@@ -175,6 +175,18 @@ inline void get(Dev<T> &d, const std::string &msg, size_t section, size_t first,
                 size_t dev_first = 0) {
     upload_string_at(d, dev_first, msg, section + first * per * sizeof(T), count * per * sizeof(T));
 }
+// `nsec` consecutive sections of n elements each (the message from byte `section` on) against a buffer that holds the
+// member's `count` elements of every section back to back: one copy when the member has the whole vector
+template <class T>
+inline void put_sections(const Dev<T> &d, std::string &msg, size_t section, size_t nsec, size_t n, size_t first, size_t count) {
+    if (count == n) return put(d, msg, section, 0, nsec * n);
+    for (size_t k = 0; k < nsec; k++) put(d, msg, section + k * n * sizeof(T), first, count, 1, k * count);
+}
+template <class T>
+inline void get_sections(Dev<T> &d, const std::string &msg, size_t section, size_t nsec, size_t n, size_t first, size_t count) {
+    if (count == n) return get(d, msg, section, 0, nsec * n);
+    for (size_t k = 0; k < nsec; k++) get(d, msg, section + k * n * sizeof(T), first, count, 1, k * count);
+}
 // host vector -> one device buffer per member, and back
 template <class E, class T> inline void scatter(E &e, const T *host, size_t n, size_t per, Bufs<T> &d) {
     run(e, n, [&](mpcx_ctx *ctx, int m, uint64_t i0, uint64_t cnt) { fresh(d[m], ctx, per * cnt).up(host + per * i0, per * cnt); });
