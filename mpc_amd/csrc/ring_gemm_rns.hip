@@ -699,6 +699,7 @@ int ring_gemm_parts_rns(mpcx_ctx *ctx, const GemmPart *parts, int nparts, u64 r,
     i8 *Bpl = Apl + ((NP * Mp * Kp + 255) & ~255ull);
     u8 *Y = (u8 *)Bpl + ((NP * Np * Kp + 255) & ~255ull);
     const u32 tiles_m = (u32)(geom.wide ? ceil_div(Mp, TMW) : Mp / TM), tiles_n = (u32)(Np / TN);
+    MPCX_REQUIRE((u64)tiles_m * tiles_n * NP < (1ull << 31), "ring gemm: too many output tiles for one launch");
     const u32 nkb = (u32)(Kp / RK);
     const u64 soA = layA ? 1 : l, skA = layA ? r : 1;
     const u64 soB = layB ? l : 1, skB = layB ? 1 : c;
