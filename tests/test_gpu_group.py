@@ -141,3 +141,24 @@ def test_checkpoint_tables_are_shared_through_the_disk_cache(tmp_path):
     files[0].write_bytes(data[:32] + bytes(len(data) - 32))  # right header, wrong states: rejected by the first entry
     fourth = run(env)
     assert fourth.returncode == 0 and fourth.stdout == first.stdout
+
+
+@pytest.mark.parametrize("nbytes", [1, 4095, (4 << 20) - 1, 4 << 20, (4 << 20) + 1, (12 << 20) - 3, (37 << 20) + 5])
+def test_host_device_copies_round_trip(nbytes):
+    """mpcx_h2d / mpcx_d2h (plain below 4 MiB, pipelined through the pinned staging buffers above, ragged last chunks)
+    and mpcx_host_copy (the multi-threaded memcpy) return exactly the bytes they were given."""
+    from mpc_amd import Context, load_library
+    ctx = Context(0)
+    rng = np.random.default_rng(nbytes)
+    src = rng.integers(0, 256, nbytes + 9, dtype=np.uint8)[9:]  # an odd host alignment as well
+    d = ctx.to_device(src)
+    assert np.array_equal(d.to_host(), src)
+    # device to device through a second buffer, then back: the staged download of a buffer the staged upload filled
+    e = ctx.to_device(np.zeros(nbytes, np.uint8))
+    ctx.call("d2d", e, d, nbytes)
+    assert np.array_equal(e.to_host(), src)
+    dst = np.zeros(nbytes, np.uint8)
+    lib = load_library()
+    assert lib.mpcx_host_copy(ctypes.c_void_p(dst.ctypes.data), ctypes.c_void_p(src.ctypes.data), U64(nbytes)) == 0
+    assert np.array_equal(dst, src)
+    ctx.close()
