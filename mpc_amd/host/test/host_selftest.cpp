@@ -325,7 +325,7 @@ static void my_party(InProcHub *hub, size_t p) {
         VecI64 X(n), Xj, Zj, Z;
         vecbool Aj, A;
         for (size_t i = 0; i < n; i++) X[i] = g.pop_int64() / 2;
-        X[0] = 0, X[1] = -1, X[2] = -2, X[3] = (int64_t)-1 << 62, X[4] = ((int64_t)1 << 62) - 1;
+        X[0] = 0, X[1] = -1, X[2] = -2, X[3] = -((int64_t)1 << 62), X[4] = ((int64_t)1 << 62) - 1;
         e.share(X, Xj);
         if (p != 2) Xj[2] = -1; // test/test_Myengine.cpp:170: both shares -1, the value stays -2
         e.msb(Xj, Aj);
