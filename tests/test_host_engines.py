@@ -34,6 +34,16 @@ def test_wire_codecs_round_trip_and_byte_positions():
     assert r.returncode == 0 and "all checks passed" in r.stdout, r.stdout + r.stderr
 
 
+def test_in_process_messenger_and_host_copy():
+    """Three party threads, sixty rounds, payloads from empty to 3 MiB through InProcMessenger and the library's
+    multi-threaded host copy (no GPU involved): every received message is what its sender posted."""
+    exe = os.path.join(HOST, "inproc_selftest")
+    if not os.path.exists(exe):
+        pytest.skip("host tools not built")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "all checks passed" in r.stdout, r.stdout + r.stderr
+
+
 def test_host_headers_keep_the_reference_surface():
     """Same class / method / member names as mpc_engine/ABY3Engine.hpp:24-54 and SecurennEngine.hpp:20-50."""
     a = open(os.path.join(HOST, "mpc_engine", "ABY3Engine.hpp")).read()
