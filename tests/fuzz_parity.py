@@ -1,0 +1,140 @@
+"""Randomised parity campaign (run by hand on a GPU box: `python tests/fuzz_parity.py [iterations] [seed]`; not collected
+by pytest).  Every iteration draws one case -- a ring product of random shape / layouts / formulation / block tile, an
+ABY3 ReLU chain, a SecureNN msb or a MyEngine ReLU chain of random length, whole or cut into random element ranges,
+with the fused or the separate segment calls and the generator-byte cache on or off -- runs it on the HIP path and on
+the CPU oracle and requires identical messages and shares."""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+import my_protocols as mp  # noqa: E402
+import protocols as pr  # noqa: E402
+from backends import GpuBackend, OracleBackend  # noqa: E402
+from my_backends import GpuMy, OracleMy  # noqa: E402
+from oracle_lib import prg_pops  # noqa: E402
+from range_helpers import aby3_relu, run_in_ranges, same_logs, snn_msb  # noqa: E402
+
+
+def rnd(rng, n):
+    return rng.integers(-2 ** 63, 2 ** 63, int(n), dtype=np.int64)
+
+
+def random_ranges(rng, n):
+    """Cuts [0, n) into 1..4 contiguous ranges (some possibly of one element)."""
+    k = int(rng.integers(1, 5))
+    cuts = sorted(set(int(c) for c in rng.integers(1, max(2, n), k - 1))) if n > 1 else []
+    edges = [0] + [c for c in cuts if 0 < c < n] + [n]
+    return tuple((a, b - a) for a, b in zip(edges, edges[1:]))
+
+
+def case_gemm(rng, gpu, orc):
+    r, l, c = (int(v) for v in rng.integers(1, 701, 3))
+    if rng.random() < 0.2:
+        l = int(rng.integers(700, 3000))
+    la, lb, lc, acc = (int(v) for v in rng.integers(0, 2, 4))
+    os.environ["MPCX_GEMM_RNS"] = str(rng.choice(["0", "2", "1"]))
+    os.environ["MPCX_RNS_TILE"] = str(rng.choice(["0", "1"]))
+    A, B = rnd(rng, r * l), rnd(rng, l * c)
+    if rng.random() < 0.3:  # extreme digits
+        A[:: max(1, A.size // 50)] = np.int64(-0x7F7F7F7F7F7F7F80)
+        B[:: max(1, B.size // 50)] = np.int64(0x7F7F7F7F7F7F7F7F)
+    C = rnd(rng, r * c) if acc else None
+    got = gpu.ring_gemm(A, B, r, l, c, la, lb, lc, C=C)
+    want = orc.ring_gemm(A, B, r, l, c, la, lb, lc, C=C)
+    assert np.array_equal(got, want), ("gemm", r, l, c, la, lb, lc, acc, os.environ["MPCX_GEMM_RNS"], os.environ["MPCX_RNS_TILE"])
+    return f"gemm {r}x{l}x{c} lay {la}{lb}{lc} acc {acc} rns {os.environ['MPCX_GEMM_RNS']} tile {os.environ['MPCX_RNS_TILE']}"
+
+
+def case_aby3_relu(rng, gpu, orc):
+    n = int(rng.integers(1, 30000))
+    pr.MSB_FUSED = bool(rng.integers(0, 2))
+    x = rnd(rng, n)
+    x[: min(n, 6)] = np.array([0, -1, 1, -2 ** 63, 2 ** 63 - 1, -2], dtype=np.int64)[: min(n, 6)]
+    wo = pr.World(orc)
+    want = aby3_relu(wo, x)
+    ranges = random_ranges(rng, n)
+    got, log = run_in_ranges(gpu, aby3_relu, x, ranges, halves=2)
+    same_logs(log, wo.log)
+    for j in range(3):
+        assert np.array_equal(got[j], want[j]), ("aby3 relu", n, ranges, j)
+    return f"aby3 relu n {n} ranges {ranges} fused {pr.MSB_FUSED}"
+
+
+def case_snn_msb(rng, gpu, orc):
+    n = int(rng.integers(1, 20000))
+    pr.SNN_FUSED = bool(rng.integers(0, 2))
+    cache = bool(rng.integers(0, 2))
+    gpu.ctx.call("set_rand_cache", (4 << 30) if cache else 0)
+    a = rnd(rng, n) >> 1
+    a[: min(n, 4)] = np.array([0, -1, -(1 << 62), (1 << 62) - 1], dtype=np.int64)[: min(n, 4)]
+    wo = pr.World(orc)
+    want = snn_msb(wo, a)
+    ranges = random_ranges(rng, n)
+    got, log = run_in_ranges(gpu, snn_msb, a, ranges)
+    same_logs(log, wo.log)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), ("snn msb", n, ranges)
+    assert np.array_equal((got[0].view(np.uint64) + got[1].view(np.uint64)).view(np.int64), (a < 0).astype(np.int64))
+    return f"snn msb n {n} ranges {ranges} fused {pr.SNN_FUSED} cache {cache}"
+
+
+def case_pc(rng, gpu, orc):
+    n = int(rng.integers(1, 5000))
+    cache = bool(rng.integers(0, 2))
+    gpu.ctx.call("set_rand_cache", (4 << 30) if cache else 0)
+    hi = 67 if rng.random() < 0.5 else 65536  # the protocol's domain, or arbitrary 16-bit shares
+    xb = rng.integers(0, hi, 64 * n, dtype=np.uint16)
+    beta = rng.integers(0, 2, n, dtype=np.int8) if hi == 67 else rng.integers(-2, 3, n, dtype=np.int8)
+    r = rnd(rng, n)
+    r[:: int(rng.integers(2, 9))] = -1
+    nt = n + int(rng.integers(0, 1000))
+    i0 = int(rng.integers(0, nt - n + 1))
+    from oracle_lib import KEY01
+    for party in (0, 1):
+        assert np.array_equal(gpu.snn_pc_party(party, xb, beta, r, nt, i0, KEY01),
+                              orc.snn_pc_party(party, xb, beta, r, nt, i0, KEY01)), ("pc", n, nt, i0, hi, cache, party)
+    return f"pc n {n} of {nt} at {i0} domain {hi} cache {cache}"
+
+
+def case_my_relu(rng, gmy, omy):
+    n = int(rng.integers(1, 20000))
+    X = rnd(rng, n) // 2
+    res = []
+    for be in (gmy, omy):
+        w = pr.World(be)
+        Xs = mp.my_share(w, X, n)
+        A = mp.my_msb(w, Xs)
+        Z = mp.my_bit_inject(w, Xs, A)
+        res.append((w, A, Z))
+    same_logs(res[0][0].log, res[1][0].log)
+    for j in range(2):
+        assert np.array_equal(res[0][1][j], res[1][1][j]) and np.array_equal(res[0][2][j], res[1][2][j]), ("my relu", n, j)
+    return f"my relu n {n}"
+
+
+def main():
+    iters = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    rng = np.random.default_rng(seed)
+    gpu, orc, gmy, omy = GpuBackend(), OracleBackend(), GpuMy(), OracleMy()
+    cases = [(case_gemm, (gpu, orc), 0.35), (case_aby3_relu, (gpu, orc), 0.2), (case_snn_msb, (gpu, orc), 0.2),
+             (case_pc, (gpu, orc), 0.15), (case_my_relu, (gmy, omy), 0.1)]
+    p = np.array([c[2] for c in cases])
+    t0 = time.time()
+    for it in range(iters):
+        fn, args, _ = cases[int(rng.choice(len(cases), p=p / p.sum()))]
+        desc = fn(rng, *args)
+        if it % 10 == 0 or time.time() - t0 > 30:
+            print(f"[{it}] ok: {desc}", flush=True)
+            t0 = time.time()
+    for k in ("MPCX_GEMM_RNS", "MPCX_RNS_TILE"):
+        os.environ.pop(k, None)
+    print(f"fuzz_parity: {iters} cases passed (seed {seed})", flush=True)
+
+
+if __name__ == "__main__":
+    main()
