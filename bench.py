@@ -460,8 +460,8 @@ def bitwise_rates(ctx, torch, dev, log2n=24, rank=0, world=1, tables=None):
         Xs = pr.aby3_share(w, xD, n)
         Gs, Ps = pr.aby3_add_prepare(w, Xs)
         Zb = pr.aby3_msb(w, Gs, Ps)
-        C = pr.aby3_bit_inject(w, Xs, Zb)
-        return [be.ring_sub(Xs[j][0], C[j][0]) for j in range(3)]
+        R = pr.aby3_bit_inject(w, Xs, Zb, minuend=Xs)  # both result shares of every party: x - bit_inject(x, msb)
+        return [R[j][0] for j in range(3)]
 
     aby3_relu()
     be.events = []

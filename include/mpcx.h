@@ -210,6 +210,22 @@ int mpcx_aby3_bit_inject_p2_pre(mpcx_ctx *ctx, const int8_t *B0, const int8_t *B
 int mpcx_aby3_bit_inject_p2_post(mpcx_ctx *ctx, const int8_t *B0, const int8_t *B1, uint64_t n_total, uint64_t i0,
                                  uint64_t n, uint64_t seed20, uint64_t pop20, uint64_t seed12, uint64_t pop12,
                                  const int64_t *from_p0, const int64_t *from_p1, int64_t *C0, int64_t *C1);
+/* The ReLU composition x - bit_inject(x, msb(add_prepare(x))) (benchmark/benchmark1.cpp:71-73 followed by the
+ * subtraction of the two share vectors): the post segment of bit_inject fused with that subtraction.  Same
+ * arguments as the post call of the party plus the minuend shares S0 / S1; R_k = S_k - C_k, where C_k is what the
+ * post call would have written.  R may be the same array as S. */
+int mpcx_aby3_bit_inject_p0_post_sub(mpcx_ctx *ctx, const int8_t *B0, uint64_t n_total, uint64_t i0, uint64_t n,
+                                     uint64_t seed01, uint64_t pop01, uint64_t seed20, uint64_t pop20,
+                                     const int64_t *from_p1, const int64_t *from_p2, const int64_t *S0,
+                                     const int64_t *S1, int64_t *R0, int64_t *R1);
+int mpcx_aby3_bit_inject_p1_post_sub(mpcx_ctx *ctx, const int8_t *B1, uint64_t n_total, uint64_t i0, uint64_t n,
+                                     uint64_t seed01, uint64_t pop01, uint64_t seed12, uint64_t pop12,
+                                     const int64_t *from_p0, const int64_t *from_p2, const int64_t *S0,
+                                     const int64_t *S1, int64_t *R0, int64_t *R1);
+int mpcx_aby3_bit_inject_p2_post_sub(mpcx_ctx *ctx, const int8_t *B0, const int8_t *B1, uint64_t n_total, uint64_t i0,
+                                     uint64_t n, uint64_t seed20, uint64_t pop20, uint64_t seed12, uint64_t pop12,
+                                     const int64_t *from_p0, const int64_t *from_p1, const int64_t *S0,
+                                     const int64_t *S1, int64_t *R0, int64_t *R1);
 
 /* ---- SecurennEngine (mpc_engine/SecurennEngine.cpp) ---- */
 /* share (:318-334): party 0: -pop(s01); party 1: X + pop(s01); party 2: zeros */

@@ -18,6 +18,7 @@ def _c(a, dt):
 class GpuBackend:
     """Same surface as OracleBackend, executed by libmpcx.so on cuda:0 (no fallback of any kind)."""
     name = "gpu"
+    bit_inject_post_takes_minuend = True  # aby3_bit_inject_p*_post(..., sub=(S0, S1)) -> mpcx_aby3_bit_inject_p*_post_sub
 
     def __init__(self, ctx=None):
         from mpc_amd import Context
@@ -185,11 +186,17 @@ class GpuBackend:
         return self._go("aby3_bit_inject_p0_pre", _c(A0, np.int64), _c(B0, np.int8), _c(B1, np.int8), nt, i0, n, seed01,
                         pop01, seed20, pop20, ("out", np.int64, 2 * n), ("out", np.int64, 3 * n))
 
-    def aby3_bit_inject_p0_post(self, B0, seed01, pop01, seed20, pop20, from1, from2, rng=None):
+    # sub = (S0, S1): the post segment fused with the ReLU subtraction, returns S_k - C_k instead of C_k
+    @staticmethod
+    def _minuend(sub):
+        return ("_post_sub", [_c(sub[0], np.int64), _c(sub[1], np.int64)]) if sub is not None else ("_post", [])
+
+    def aby3_bit_inject_p0_post(self, B0, seed01, pop01, seed20, pop20, from1, from2, rng=None, sub=None):
         n = B0.size
         nt, i0 = rng or (n, 0)
-        return self._go("aby3_bit_inject_p0_post", _c(B0, np.int8), nt, i0, n, seed01, pop01, seed20, pop20,
-                        _c(from1, np.int64), _c(from2, np.int64), ("out", np.int64, n), ("out", np.int64, n))
+        tail, S = self._minuend(sub)
+        return self._go("aby3_bit_inject_p0" + tail, _c(B0, np.int8), nt, i0, n, seed01, pop01, seed20, pop20,
+                        _c(from1, np.int64), _c(from2, np.int64), *S, ("out", np.int64, n), ("out", np.int64, n))
 
     def aby3_bit_inject_p1_pre(self, A0, A1, B0, B1, seed01, pop01, seed12, pop12, rng=None):
         n = A0.size
@@ -197,11 +204,12 @@ class GpuBackend:
         return self._go("aby3_bit_inject_p1_pre", _c(A0, np.int64), _c(A1, np.int64), _c(B0, np.int8), _c(B1, np.int8),
                         nt, i0, n, seed01, pop01, seed12, pop12, ("out", np.int64, 2 * n), ("out", np.int64, 3 * n))
 
-    def aby3_bit_inject_p1_post(self, B1, seed01, pop01, seed12, pop12, from0, from2, rng=None):
+    def aby3_bit_inject_p1_post(self, B1, seed01, pop01, seed12, pop12, from0, from2, rng=None, sub=None):
         n = B1.size
         nt, i0 = rng or (n, 0)
-        return self._go("aby3_bit_inject_p1_post", _c(B1, np.int8), nt, i0, n, seed01, pop01, seed12, pop12,
-                        _c(from0, np.int64), _c(from2, np.int64), ("out", np.int64, n), ("out", np.int64, n))
+        tail, S = self._minuend(sub)
+        return self._go("aby3_bit_inject_p1" + tail, _c(B1, np.int8), nt, i0, n, seed01, pop01, seed12, pop12,
+                        _c(from0, np.int64), _c(from2, np.int64), *S, ("out", np.int64, n), ("out", np.int64, n))
 
     def aby3_bit_inject_p2_pre(self, B0, B1, seed20, pop20, seed12, pop12, rng=None):
         n = B0.size
@@ -209,12 +217,12 @@ class GpuBackend:
         return self._go("aby3_bit_inject_p2_pre", _c(B0, np.int8), _c(B1, np.int8), nt, i0, n, seed20, pop20, seed12, pop12,
                         ("out", np.int64, n), ("out", np.int64, n))
 
-    def aby3_bit_inject_p2_post(self, B0, B1, seed20, pop20, seed12, pop12, from0, from1, rng=None):
+    def aby3_bit_inject_p2_post(self, B0, B1, seed20, pop20, seed12, pop12, from0, from1, rng=None, sub=None):
         n = B0.size
         nt, i0 = rng or (n, 0)
-        return self._go("aby3_bit_inject_p2_post", _c(B0, np.int8), _c(B1, np.int8), nt, i0, n, seed20, pop20, seed12,
-                        pop12,
-                        _c(from0, np.int64), _c(from1, np.int64), ("out", np.int64, n), ("out", np.int64, n))
+        tail, S = self._minuend(sub)
+        return self._go("aby3_bit_inject_p2" + tail, _c(B0, np.int8), _c(B1, np.int8), nt, i0, n, seed20, pop20, seed12,
+                        pop12, _c(from0, np.int64), _c(from1, np.int64), *S, ("out", np.int64, n), ("out", np.int64, n))
 
     # ---- SecureNN
     def snn_share_local(self, party, X, n, seed01, pop01):

@@ -555,20 +555,7 @@ struct BiGeom {
     u64 c(u64 base) const { return base + i0; }
     u64 w(u64 base) const { return base + nt + 2 * i0; }
 };
-// A generator positioned anywhere in a stream: starts from the checkpoint below word t and discards the words in
-// between.  Every lane of a launch opens a section at words that differ by multiples of PRG_CK, so the number of
-// discarded words is the same for all of them.
-struct BiGen {
-    u64 s = 0, l = 0, h = 0;
-    __device__ void open(const PrgCk *__restrict__ ck, u64 t, bool active) {
-        if (active) {
-            const PrgCk c = ck[t / PRG_CK];
-            s = c.seed, l = c.lcg, h = c.hash;
-        }
-        for (u32 i = 0; i < (u32)(t % PRG_CK); i++) prv_step(s, l, h);
-    }
-    __device__ u64 next() { return prv_step(s, l, h); }
-};
+using BiGen = PrgCursor; // a generator positioned anywhere in a stream (prg_map.h)
 struct BiSenderArgs {
     const PrgCk *ckCa, *ckCb, *ckW1, *ckW2, *ckWs; // checkpoint tables of the five stream sections
     u64 tCa, tCb, tW1, tW2, tWs;                   // stream word of element 0 of the call in each section
@@ -746,6 +733,100 @@ __global__ __launch_bounds__(256) void bi_helper_pre_kernel(BiHelperArgs P) {
     }
 }
 
+// The segment after the round (party 0: ABY3Engine.cpp:621-682, party 1: :791-850, party 2: :923-1020) in one pass.
+// Output share k of element e is
+//     C_k[e] = G_k[e] + ((sel_k[e] == 1 ? hi_k[e] : lo_k[e]) ^ x_k[e])
+// where G_k is one C word of a stream section or the sum of two (the shares the senders kept), and the second term
+// -- the message the receiver unmasks with the helper's word (:660, :811, :963, :996) -- is present when sel_k is
+// non-null.  With sub_k non-null the pass stores sub_k[e] - C_k[e] instead: the ReLU composition x - bit_inject(x, msb)
+// (benchmark/benchmark1.cpp:71-73 followed by the subtraction) without writing C and reading it back.
+// Geometry of bi_sender_pre_kernel: a lane owns 64 consecutive elements and the generators of both outputs, works in
+// windows of 16 elements and hands one output of a window at a time to the wavefront through LDS; the wavefront
+// visits it in memory order, so the message words, the select bytes and the stores run in 128-byte pieces.
+struct BiPostArgs {
+    const PrgCk *ck[2][2]; // generators of G_k: ck[k][0], plus ck[k][1] when non-null
+    u64 t[2][2];           // stream word of element 0 of the call in each section
+    const i8 *sel[2];
+    const u64 *lo[2], *hi[2], *x[2];
+    const u64 *sub[2];
+    u64 *out[2];
+    u64 n;
+};
+// one output of a window: TWO = G_k is the sum of two sections, SEL = the unmasked message is added, SUB = the minuend.
+// Both candidate message words are loaded and one is chosen afterwards, so that no load waits for the select byte;
+// the arrays are compile-time present or absent, which lets the loads of four elements run together.
+template <bool TWO, bool SEL, bool SUB>
+__device__ inline void bi_post_pass(const BiPostArgs &P, const u32 k, BiGen &ga, BiGen &gb, u64 *tile, u64 *row_tile,
+                                    const u32 tid, const u64 lane0, const u32 win) {
+    constexpr u32 EPL = 64, WIN = 16, PITCH = WIN + 1;
+#pragma unroll
+    for (u32 j = 0; j < WIN; j++) row_tile[j] = TWO ? ga.next() + gb.next() : ga.next();
+    prg_wave_sync();
+    const i8 *__restrict__ sel = P.sel[k];
+    const u64 *__restrict__ lo = P.lo[k], *__restrict__ hi = P.hi[k], *__restrict__ x = P.x[k];
+    const u64 *__restrict__ sub = P.sub[k];
+    u64 *__restrict__ out = P.out[k];
+#pragma unroll 4
+    for (u32 j = 0; j < WIN; j++) {
+        const u32 idx = j * 64 + (tid & 63);
+        const u32 row = (tid & ~63u) + idx / WIN, col = idx % WIN;
+        const u64 e = (lane0 + row) * EPL + win * WIN + col;
+        if (e < P.n) {
+            u64 v = tile[row * PITCH + col];
+            if (SEL) {
+                const u64 m0 = lo[e], m1 = hi[e], w = x[e];
+                v += (sel[e] == 1 ? m1 : m0) ^ w;
+            }
+            if (SUB) v = sub[e] - v;
+            out[e] = v;
+        }
+    }
+    prg_wave_sync();
+}
+// PARTY 0: output 0 = one section + message, output 1 = two sections; PARTY 1: the other way round; PARTY 2: both
+// outputs one section + message.
+template <int PARTY, bool SUB> __global__ __launch_bounds__(256) void bi_post_kernel(BiPostArgs P) {
+    constexpr u32 EPL = 64, WIN = 16, PITCH = WIN + 1;
+    constexpr bool TWO0 = PARTY == 1, TWO1 = PARTY == 0;
+    __shared__ u64 tile[256 * PITCH];
+    const u32 tid = threadIdx.x;
+    const u64 lane0 = (u64)blockIdx.x * 256;
+    const u64 e0 = (lane0 + tid) * EPL;
+    const bool active = e0 < P.n;
+    BiGen g[2][2];
+    g[0][0].open(P.ck[0][0], P.t[0][0] + e0, active);
+    if (TWO0) g[0][1].open(P.ck[0][1], P.t[0][1] + e0, active);
+    g[1][0].open(P.ck[1][0], P.t[1][0] + e0, active);
+    if (TWO1) g[1][1].open(P.ck[1][1], P.t[1][1] + e0, active);
+    u64 *row_tile = tile + tid * PITCH;
+#pragma unroll 1
+    for (u32 win = 0; win < EPL / WIN; win++) {
+        bi_post_pass<TWO0, !TWO0, SUB>(P, 0, g[0][0], g[0][1], tile, row_tile, tid, lane0, win);
+        bi_post_pass<TWO1, !TWO1, SUB>(P, 1, g[1][0], g[1][1], tile, row_tile, tid, lane0, win);
+    }
+}
+int bi_post_launch(mpcx_ctx *ctx, int party, const BiPostArgs &P) {
+    const u64 grid = ceil_div(ceil_div(P.n, 64), 256);
+    MPCX_REQUIRE(grid < (1ull << 31), "bit_inject: range too large for one launch");
+    const bool sub = P.sub[0] != nullptr;
+    ProfScope ps(ctx, PROF_PRG);
+#define BI_POST(PARTY)                                                                                                 \
+    if (sub)                                                                                                           \
+        hipLaunchKernelGGL((bi_post_kernel<PARTY, true>), dim3((u32)grid), dim3(256), 0, ctx->stream, P);              \
+    else                                                                                                               \
+        hipLaunchKernelGGL((bi_post_kernel<PARTY, false>), dim3((u32)grid), dim3(256), 0, ctx->stream, P)
+    if (party == 0) {
+        BI_POST(0);
+    } else if (party == 1) {
+        BI_POST(1);
+    } else {
+        BI_POST(2);
+    }
+#undef BI_POST
+    MPCX_LAUNCH_CHECK();
+    return 0;
+}
+
 int bi_sender_launch(mpcx_ctx *ctx, BiSenderArgs P) {
     P.aligned = (((uintptr_t)P.A0 | (uintptr_t)P.A1 | (uintptr_t)P.Bx | (uintptr_t)P.By | (uintptr_t)P.sel) & 15) == 0;
     const u64 grid = ceil_div(ceil_div(P.n, 64), 256);
@@ -783,22 +864,43 @@ int mpcx_aby3_bit_inject_p0_pre(mpcx_ctx *ctx, const int64_t *A0, const int8_t *
     P.n = n;
     return bi_sender_launch(ctx, P);
 }
+static int bi_p0_post(mpcx_ctx *ctx, const char *who, const int8_t *B0, uint64_t n_total, uint64_t i0, uint64_t n,
+                      uint64_t seed01, uint64_t pop01, uint64_t seed20, uint64_t pop20, const int64_t *from_p1,
+                      const int64_t *from_p2, const int64_t *S0, const int64_t *S1, int64_t *C0, int64_t *C1) {
+    MPCX_REQUIRE(i0 <= n_total && n <= n_total - i0, "%s: elements [%llu, +%llu) outside a vector of %llu", who,
+                 (unsigned long long)i0, (unsigned long long)n, (unsigned long long)n_total);
+    if (n == 0) return 0;
+    MPCX_REQUIRE(B0 && from_p1 && from_p2 && C0 && C1, "%s: NULL pointer", who);
+    const BiGeom G{n_total, i0, n};
+    const u64 b01 = PRG_POP_T0 + pop01, b20 = PRG_POP_T0 + pop20;
+    const PrgCk *ck01, *ck20;
+    MPCX_TRY(mpcx_prg_table(ctx, seed01, 0, b01 + 6 * n_total, &ck01));
+    MPCX_TRY(mpcx_prg_table(ctx, seed20, 0, b20 + 3 * n_total, &ck20));
+    const u64 *f1 = (const u64 *)from_p1, *f2 = (const u64 *)from_p2;
+    BiPostArgs P{};
+    // A0j[0] + A12j[0] = C02 + (m_b ^ w_b)  (:660, :679)
+    P.ck[0][0] = ck20, P.t[0][0] = G.c(b20);
+    P.sel[0] = B0, P.lo[0] = f1, P.hi[0] = f1 + n, P.x[0] = f2;
+    // A0j[1] + A12j[1] = C01 + C10
+    P.ck[1][0] = ck01, P.t[1][0] = G.c(b01);
+    P.ck[1][1] = ck01, P.t[1][1] = G.c(b01 + 3 * n_total);
+    P.sub[0] = (const u64 *)S0, P.sub[1] = (const u64 *)S1;
+    P.out[0] = (u64 *)C0, P.out[1] = (u64 *)C1, P.n = n;
+    return bi_post_launch(ctx, 0, P);
+}
 int mpcx_aby3_bit_inject_p0_post(mpcx_ctx *ctx, const int8_t *B0, uint64_t n_total, uint64_t i0, uint64_t n,
                                  uint64_t seed01, uint64_t pop01, uint64_t seed20, uint64_t pop20,
                                  const int64_t *from_p1, const int64_t *from_p2, int64_t *C0, int64_t *C1) {
-    BI_RANGE_CHECK("mpcx_aby3_bit_inject_p0_post");
-    if (n == 0) return 0;
-    MPCX_REQUIRE(B0 && from_p1 && from_p2 && C0 && C1, "mpcx_aby3_bit_inject_p0_post: NULL pointer");
-    const BiGeom G{n_total, i0, n};
-    const u64 b01 = PRG_POP_T0 + pop01, b20 = PRG_POP_T0 + pop20;
-    const u64 *f1 = (const u64 *)from_p1, *f2 = (const u64 *)from_p2;
-    u64 *o0 = (u64 *)C0, *o1 = (u64 *)C1;
-    MPCX_TRY(prg_map1(ctx, seed20, G.c(b20), n, [=] __device__(u64 i, u64 c02) {
-        const u64 a12 = (B0[i] == 1 ? f1[n + i] : f1[i]) ^ f2[i]; // :660
-        o0[i] = c02 + a12;                                        // A0j[0] + A12j[0]
-    }));
-    return prg_map2(ctx, seed01, G.c(b01), seed01, G.c(b01 + 3 * n_total), n, [] __device__(u64 a, u64 b) { return a + b; },
-                    [=] __device__(u64 i, u64 v) { o1[i] = v; }); // A0j[1] + A12j[1] = C01 + C10
+    return bi_p0_post(ctx, "mpcx_aby3_bit_inject_p0_post", B0, n_total, i0, n, seed01, pop01, seed20, pop20, from_p1, from_p2,
+                      nullptr, nullptr, C0, C1);
+}
+int mpcx_aby3_bit_inject_p0_post_sub(mpcx_ctx *ctx, const int8_t *B0, uint64_t n_total, uint64_t i0, uint64_t n,
+                                     uint64_t seed01, uint64_t pop01, uint64_t seed20, uint64_t pop20,
+                                     const int64_t *from_p1, const int64_t *from_p2, const int64_t *S0,
+                                     const int64_t *S1, int64_t *R0, int64_t *R1) {
+    MPCX_REQUIRE((S0 && S1) || n == 0, "mpcx_aby3_bit_inject_p0_post_sub: NULL minuend");
+    return bi_p0_post(ctx, "mpcx_aby3_bit_inject_p0_post_sub", B0, n_total, i0, n, seed01, pop01, seed20, pop20, from_p1,
+                      from_p2, S0, S1, R0, R1);
 }
 int mpcx_aby3_bit_inject_p1_pre(mpcx_ctx *ctx, const int64_t *A0, const int64_t *A1, const int8_t *B0,
                                 const int8_t *B1, uint64_t n_total, uint64_t i0, uint64_t n, uint64_t seed01,
@@ -823,22 +925,43 @@ int mpcx_aby3_bit_inject_p1_pre(mpcx_ctx *ctx, const int64_t *A0, const int64_t 
     P.n = n;
     return bi_sender_launch(ctx, P);
 }
+static int bi_p1_post(mpcx_ctx *ctx, const char *who, const int8_t *B1, uint64_t n_total, uint64_t i0, uint64_t n,
+                      uint64_t seed01, uint64_t pop01, uint64_t seed12, uint64_t pop12, const int64_t *from_p0,
+                      const int64_t *from_p2, const int64_t *S0, const int64_t *S1, int64_t *C0, int64_t *C1) {
+    MPCX_REQUIRE(i0 <= n_total && n <= n_total - i0, "%s: elements [%llu, +%llu) outside a vector of %llu", who,
+                 (unsigned long long)i0, (unsigned long long)n, (unsigned long long)n_total);
+    if (n == 0) return 0;
+    MPCX_REQUIRE(B1 && from_p0 && from_p2 && C0 && C1, "%s: NULL pointer", who);
+    const BiGeom G{n_total, i0, n};
+    const u64 b01 = PRG_POP_T0 + pop01, b12 = PRG_POP_T0 + pop12;
+    const PrgCk *ck01, *ck12;
+    MPCX_TRY(mpcx_prg_table(ctx, seed01, 0, b01 + 6 * n_total, &ck01));
+    MPCX_TRY(mpcx_prg_table(ctx, seed12, 0, b12 + 3 * n_total, &ck12));
+    const u64 *f0 = (const u64 *)from_p0, *f2 = (const u64 *)from_p2;
+    BiPostArgs P{};
+    // A0j[0] + A12j[0] = C01 + C10
+    P.ck[0][0] = ck01, P.t[0][0] = G.c(b01);
+    P.ck[0][1] = ck01, P.t[0][1] = G.c(b01 + 3 * n_total);
+    // A0j[1] + A12j[1] = (m_b ^ w_b) + C12  (:811)
+    P.ck[1][0] = ck12, P.t[1][0] = G.c(b12);
+    P.sel[1] = B1, P.lo[1] = f0, P.hi[1] = f0 + n, P.x[1] = f2;
+    P.sub[0] = (const u64 *)S0, P.sub[1] = (const u64 *)S1;
+    P.out[0] = (u64 *)C0, P.out[1] = (u64 *)C1, P.n = n;
+    return bi_post_launch(ctx, 1, P);
+}
 int mpcx_aby3_bit_inject_p1_post(mpcx_ctx *ctx, const int8_t *B1, uint64_t n_total, uint64_t i0, uint64_t n,
                                  uint64_t seed01, uint64_t pop01, uint64_t seed12, uint64_t pop12,
                                  const int64_t *from_p0, const int64_t *from_p2, int64_t *C0, int64_t *C1) {
-    BI_RANGE_CHECK("mpcx_aby3_bit_inject_p1_post");
-    if (n == 0) return 0;
-    MPCX_REQUIRE(B1 && from_p0 && from_p2 && C0 && C1, "mpcx_aby3_bit_inject_p1_post: NULL pointer");
-    const BiGeom G{n_total, i0, n};
-    const u64 b01 = PRG_POP_T0 + pop01, b12 = PRG_POP_T0 + pop12;
-    const u64 *f0 = (const u64 *)from_p0, *f2 = (const u64 *)from_p2;
-    u64 *o0 = (u64 *)C0, *o1 = (u64 *)C1;
-    MPCX_TRY(prg_map2(ctx, seed01, G.c(b01), seed01, G.c(b01 + 3 * n_total), n, [] __device__(u64 a, u64 b) { return a + b; },
-                      [=] __device__(u64 i, u64 v) { o0[i] = v; })); // A0j[0] + A12j[0] = C01 + C10
-    return prg_map1(ctx, seed12, G.c(b12), n, [=] __device__(u64 i, u64 c12) {
-        const u64 a0 = (B1[i] == 1 ? f0[n + i] : f0[i]) ^ f2[i]; // :811
-        o1[i] = a0 + c12;                                        // A0j[1] + A12j[1]
-    });
+    return bi_p1_post(ctx, "mpcx_aby3_bit_inject_p1_post", B1, n_total, i0, n, seed01, pop01, seed12, pop12, from_p0, from_p2,
+                      nullptr, nullptr, C0, C1);
+}
+int mpcx_aby3_bit_inject_p1_post_sub(mpcx_ctx *ctx, const int8_t *B1, uint64_t n_total, uint64_t i0, uint64_t n,
+                                     uint64_t seed01, uint64_t pop01, uint64_t seed12, uint64_t pop12,
+                                     const int64_t *from_p0, const int64_t *from_p2, const int64_t *S0,
+                                     const int64_t *S1, int64_t *R0, int64_t *R1) {
+    MPCX_REQUIRE((S0 && S1) || n == 0, "mpcx_aby3_bit_inject_p1_post_sub: NULL minuend");
+    return bi_p1_post(ctx, "mpcx_aby3_bit_inject_p1_post_sub", B1, n_total, i0, n, seed01, pop01, seed12, pop12, from_p0,
+                      from_p2, S0, S1, R0, R1);
 }
 int mpcx_aby3_bit_inject_p2_pre(mpcx_ctx *ctx, const int8_t *B0, const int8_t *B1, uint64_t n_total, uint64_t i0,
                                 uint64_t n, uint64_t seed20, uint64_t pop20, uint64_t seed12, uint64_t pop12,
@@ -860,23 +983,44 @@ int mpcx_aby3_bit_inject_p2_pre(mpcx_ctx *ctx, const int8_t *B0, const int8_t *B
     MPCX_LAUNCH_CHECK();
     return 0;
 }
+static int bi_p2_post(mpcx_ctx *ctx, const char *who, const int8_t *B0, const int8_t *B1, uint64_t n_total, uint64_t i0,
+                      uint64_t n, uint64_t seed20, uint64_t pop20, uint64_t seed12, uint64_t pop12,
+                      const int64_t *from_p0, const int64_t *from_p1, const int64_t *S0, const int64_t *S1, int64_t *C0,
+                      int64_t *C1) {
+    MPCX_REQUIRE(i0 <= n_total && n <= n_total - i0, "%s: elements [%llu, +%llu) outside a vector of %llu", who,
+                 (unsigned long long)i0, (unsigned long long)n, (unsigned long long)n_total);
+    if (n == 0) return 0;
+    MPCX_REQUIRE(B0 && B1 && from_p0 && from_p1 && C0 && C1, "%s: NULL pointer", who);
+    const BiGeom G{n_total, i0, n};
+    const u64 b20 = PRG_POP_T0 + pop20, b12 = PRG_POP_T0 + pop12;
+    const PrgCk *ck20, *ck12;
+    MPCX_TRY(mpcx_prg_table(ctx, seed20, 0, b20 + 3 * n_total, &ck20));
+    MPCX_TRY(mpcx_prg_table(ctx, seed12, 0, b12 + 3 * n_total, &ck12));
+    const u64 *f0 = (const u64 *)from_p0, *f1 = (const u64 *)from_p1;
+    BiPostArgs P{};
+    // A0j[0] + A12j[0] = (m_b ^ w_b) + C12 with party 0's messages and party 1's word  (:963)
+    P.ck[0][0] = ck12, P.t[0][0] = G.c(b12);
+    P.sel[0] = B0, P.lo[0] = f0, P.hi[0] = f0 + n, P.x[0] = f1;
+    // A0j[1] + A12j[1] = C02 + (m_b ^ w_b) with party 1's messages and party 0's word  (:996)
+    P.ck[1][0] = ck20, P.t[1][0] = G.c(b20);
+    P.sel[1] = B1, P.lo[1] = f1 + n, P.hi[1] = f1 + 2 * n, P.x[1] = f0 + 2 * n;
+    P.sub[0] = (const u64 *)S0, P.sub[1] = (const u64 *)S1;
+    P.out[0] = (u64 *)C0, P.out[1] = (u64 *)C1, P.n = n;
+    return bi_post_launch(ctx, 2, P);
+}
 int mpcx_aby3_bit_inject_p2_post(mpcx_ctx *ctx, const int8_t *B0, const int8_t *B1, uint64_t n_total, uint64_t i0,
                                  uint64_t n, uint64_t seed20, uint64_t pop20, uint64_t seed12, uint64_t pop12,
                                  const int64_t *from_p0, const int64_t *from_p1, int64_t *C0, int64_t *C1) {
-    BI_RANGE_CHECK("mpcx_aby3_bit_inject_p2_post");
-    if (n == 0) return 0;
-    MPCX_REQUIRE(B0 && B1 && from_p0 && from_p1 && C0 && C1, "mpcx_aby3_bit_inject_p2_post: NULL pointer");
-    const BiGeom G{n_total, i0, n};
-    const u64 *f0 = (const u64 *)from_p0, *f1 = (const u64 *)from_p1;
-    u64 *o0 = (u64 *)C0, *o1 = (u64 *)C1;
-    MPCX_TRY(prg_map1(ctx, seed12, G.c(PRG_POP_T0 + pop12), n, [=] __device__(u64 i, u64 c12) {
-        const u64 a0 = (B0[i] == 1 ? f0[n + i] : f0[i]) ^ f1[i]; // :963
-        o0[i] = a0 + c12;                                        // A0j[0] + A12j[0]
-    }));
-    return prg_map1(ctx, seed20, G.c(PRG_POP_T0 + pop20), n, [=] __device__(u64 i, u64 c02) {
-        const u64 a12 = (B1[i] == 1 ? f1[2 * n + i] : f1[n + i]) ^ f0[2 * n + i]; // :996
-        o1[i] = c02 + a12;                                                         // A0j[1] + A12j[1]
-    });
+    return bi_p2_post(ctx, "mpcx_aby3_bit_inject_p2_post", B0, B1, n_total, i0, n, seed20, pop20, seed12, pop12, from_p0,
+                      from_p1, nullptr, nullptr, C0, C1);
+}
+int mpcx_aby3_bit_inject_p2_post_sub(mpcx_ctx *ctx, const int8_t *B0, const int8_t *B1, uint64_t n_total, uint64_t i0,
+                                     uint64_t n, uint64_t seed20, uint64_t pop20, uint64_t seed12, uint64_t pop12,
+                                     const int64_t *from_p0, const int64_t *from_p1, const int64_t *S0,
+                                     const int64_t *S1, int64_t *R0, int64_t *R1) {
+    MPCX_REQUIRE((S0 && S1) || n == 0, "mpcx_aby3_bit_inject_p2_post_sub: NULL minuend");
+    return bi_p2_post(ctx, "mpcx_aby3_bit_inject_p2_post_sub", B0, B1, n_total, i0, n, seed20, pop20, seed12, pop12, from_p0,
+                      from_p1, S0, S1, R0, R1);
 }
 
 } // extern "C"

@@ -31,6 +31,21 @@ __host__ __device__ inline u64 prv_step(u64 &seed, u64 &lcg, u64 &hash) {
     return lcg ^ rs;
 }
 
+// A generator positioned anywhere in a stream: starts from the checkpoint below word t and discards the words in
+// between.  Every lane of a launch opens a section at words that differ by multiples of PRG_CK, so the number of
+// discarded words is the same for all of them.
+struct PrgCursor {
+    u64 s = 0, l = 0, h = 0;
+    __device__ void open(const PrgCk *__restrict__ ck, u64 t, bool active) {
+        if (active) {
+            const PrgCk c = ck[t / PRG_CK];
+            s = c.seed, l = c.lcg, h = c.hash;
+        }
+        for (u32 i = 0; i < (u32)(t % PRG_CK); i++) prv_step(s, l, h);
+    }
+    __device__ u64 next() { return prv_step(s, l, h); }
+};
+
 // PRG_CK / 2 bytes (uint16)int_buff % 67 from one checkpoint, packed four to a word
 __device__ inline void mod67_run(const PrgCk c, int zero_to_one, u32 (&w)[PRG_CK / 8]) {
     u64 seed = c.seed, lcg = c.lcg, hash = c.hash;

@@ -306,6 +306,71 @@ __global__ __launch_bounds__(256) void bit_share_gen_kernel(const u64 *__restric
     }
 }
 
+// The dealer's triples of vector_mul (SecurennEngine.cpp:191-198) in one pass, nothing staged in memory: for party
+// section i (0, 1) element j reads int_buff[3 (i n_total + j) + {0, 1, 2}] = stream words 6 (i n_total + j) + {0, 2, 4}
+// of the self stream as A_i, B_i, C_i, and C_1 is replaced by (A_0 + A_1)(B_0 + B_1) - C_0 (:198).  A lane owns 32
+// consecutive elements (192 stream words, three checkpoint runs) and one generator per section, works in windows of
+// 16 elements whose values stay in registers, and hands one output array of a window at a time to the wavefront
+// through LDS, which stores it in memory order (128-byte runs).
+struct DealVecArgs {
+    const PrgCk *ck;
+    u64 t0, t1; // stream word of A_0[first element of the call], A_1[..]
+    u64 *out[6]; // A0 B0 C0 A1 B1 C1
+    u64 n;
+};
+__global__ __launch_bounds__(256) void beaver_deal_vec_kernel(DealVecArgs P) {
+    constexpr u32 EPL = 32, WIN = 16, PITCH = WIN + 1;
+    __shared__ u64 tile[256 * PITCH];
+    const u32 tid = threadIdx.x;
+    const u64 lane0 = (u64)blockIdx.x * 256;
+    const u64 e0 = (lane0 + tid) * EPL;
+    const bool active = e0 < P.n;
+    PrgCursor g0, g1;
+    g0.open(P.ck, P.t0 + 6 * e0, active);
+    g1.open(P.ck, P.t1 + 6 * e0, active);
+    u64 *row_tile = tile + tid * PITCH;
+    auto flush = [&](u64 *__restrict__ dst, u32 win, const u64 (&v)[WIN]) {
+#pragma unroll
+        for (u32 k = 0; k < WIN; k++) row_tile[k] = v[k];
+        prg_wave_sync();
+#pragma unroll 4
+        for (u32 j = 0; j < WIN; j++) {
+            const u32 idx = j * 64 + (tid & 63);
+            const u32 row = (tid & ~63u) + idx / WIN, col = idx % WIN;
+            const u64 e = (lane0 + row) * EPL + win * WIN + col;
+            if (e < P.n) dst[e] = tile[row * PITCH + col];
+        }
+        prg_wave_sync();
+    };
+#pragma unroll 1
+    for (u32 win = 0; win < EPL / WIN; win++) {
+        u64 a[WIN], b[WIN], c[WIN];
+#pragma unroll
+        for (u32 k = 0; k < WIN; k++) { // the odd stream words are the generator's bool_buff entries
+            a[k] = g0.next(), (void)g0.next();
+            b[k] = g0.next(), (void)g0.next();
+            c[k] = g0.next(), (void)g0.next();
+        }
+        flush(P.out[0], win, a);
+        flush(P.out[1], win, b);
+        flush(P.out[2], win, c);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (u32 k = 0; k < WIN; k++) {
+            const u64 a1 = g1.next();
+            (void)g1.next();
+            const u64 b1 = g1.next();
+            for (u32 q = 0; q < 3; q++) (void)g1.next(); // bool, the unused C word of section 1, bool
+            c[k] = (a[k] + a1) * (b[k] + b1) - c[k];
+            a[k] = a1, b[k] = b1;
+        }
+        flush(P.out[3], win, a);
+        flush(P.out[4], win, b);
+        flush(P.out[5], win, c);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 inline u32 grid_for(u64 work) {
     u64 b = ceil_div(work, 256);
     if (b > MPCX_MAX_GRID) b = MPCX_MAX_GRID;
@@ -455,16 +520,18 @@ int mpcx_snn_beaver_dealer_vecmul(mpcx_ctx *ctx, uint64_t seedS, uint64_t n_tota
     if (n == 0) return 0;
     MPCX_REQUIRE(A0 && B0 && C0 && A1 && B1 && C1, "mpcx_snn_beaver_dealer_vecmul: NULL pointer");
     MPCX_REQUIRE(i0 + n <= n_total, "mpcx_snn_beaver_dealer_vecmul: range outside the vector");
-    void *ws;
-    MPCX_TRY(mpcx_ws(ctx, 48 * n, &ws));
-    u64 *w0 = (u64 *)ws, *w1 = w0 + 3 * n;
-    MPCX_TRY(prg_fill_words(ctx, seedS, 0, 2 * (3 * i0), 3 * n, 2, (i64 *)w0, nullptr));             // :191-193, i = 0
-    MPCX_TRY(prg_fill_words(ctx, seedS, 0, 2 * (3 * (n_total + i0)), 3 * n, 2, (i64 *)w1, nullptr)); // i = 1
-    return ew_launch(ctx, n, [=] __device__(u64 j) {
-        const u64 a0 = w0[3 * j], b0 = w0[3 * j + 1], c0 = w0[3 * j + 2], a1 = w1[3 * j], b1 = w1[3 * j + 1];
-        A0[j] = (i64)a0, B0[j] = (i64)b0, C0[j] = (i64)c0, A1[j] = (i64)a1, B1[j] = (i64)b1;
-        C1[j] = (i64)((a0 + a1) * (b0 + b1) - c0); // :198
-    });
+    DealVecArgs P;
+    MPCX_TRY(mpcx_prg_table(ctx, seedS, 0, 6 * (n_total + i0 + n) + PRG_CK, &P.ck));
+    P.t0 = 6 * i0, P.t1 = 6 * (n_total + i0); // :191-193 with i = 0, 1
+    int64_t *outs[6] = {A0, B0, C0, A1, B1, C1};
+    for (int k = 0; k < 6; k++) P.out[k] = (u64 *)outs[k];
+    P.n = n;
+    const u64 grid = ceil_div(ceil_div(n, 32), 256);
+    MPCX_REQUIRE(grid < (1ull << 31), "mpcx_snn_beaver_dealer_vecmul: range too large for one launch");
+    ProfScope ps(ctx, PROF_PRG);
+    hipLaunchKernelGGL(beaver_deal_vec_kernel, dim3((u32)grid), dim3(256), 0, ctx->stream, P);
+    MPCX_LAUNCH_CHECK();
+    return 0;
 }
 int mpcx_snn_beaver_party_open_vecmul(mpcx_ctx *ctx, const int64_t *X, const int64_t *Y, const int64_t *A,
                                       const int64_t *B, uint64_t n, int64_t *E, int64_t *F) {

@@ -140,8 +140,10 @@ def aby3_msb(w, Gs, Ps):
     return [hs[j].final() for j in range(3)]
 
 
-def aby3_bit_inject(w, As, Bs):
-    """bit_inject (ABY3Engine.cpp:510-1038)."""
+def aby3_bit_inject(w, As, Bs, minuend=None):
+    """bit_inject (ABY3Engine.cpp:510-1038).  With `minuend` (share pairs S_j) the result is S_j - C_j, the ReLU
+    composition x - bit_inject(x, msb) (benchmark/benchmark1.cpp:71-73 and the subtraction): one call per party after
+    the round on backends whose post segment takes the minuend, post followed by ring_sub on the others."""
     be = w.be
     n = As[0][0].size
     nt = w.whole(n)
@@ -154,9 +156,13 @@ def aby3_bit_inject(w, As, Bs):
     m20, m21 = be.aby3_bit_inject_p2_pre(Bs[2][0], Bs[2][1], KEY20, p20_2, KEY12, p12_2, rng=rng)
     for tag, m in (("01", m01), ("02", m02), ("10", m10), ("12", m12), ("20", m20), ("21", m21)):
         w.rec("bit_inject.P%s->P%s" % (tag[0], tag[1]), m)
-    C = [be.aby3_bit_inject_p0_post(Bs[0][0], KEY01, p01_0, KEY20, p20_0, m10, m20, rng=rng),
-         be.aby3_bit_inject_p1_post(Bs[1][1], KEY01, p01_1, KEY12, p12_1, m01, m21, rng=rng),
-         be.aby3_bit_inject_p2_post(Bs[2][0], Bs[2][1], KEY20, p20_2, KEY12, p12_2, m02, m12, rng=rng)]
+    fused = minuend is not None and getattr(be, "bit_inject_post_takes_minuend", False)
+    kw = [dict(rng=rng, sub=minuend[j]) if fused else dict(rng=rng) for j in range(3)]
+    C = [be.aby3_bit_inject_p0_post(Bs[0][0], KEY01, p01_0, KEY20, p20_0, m10, m20, **kw[0]),
+         be.aby3_bit_inject_p1_post(Bs[1][1], KEY01, p01_1, KEY12, p12_1, m01, m21, **kw[1]),
+         be.aby3_bit_inject_p2_post(Bs[2][0], Bs[2][1], KEY20, p20_2, KEY12, p12_2, m02, m12, **kw[2])]
+    if minuend is not None and not fused:
+        C = [[be.ring_sub(minuend[j][k], C[j][k]) for k in range(2)] for j in range(3)]
     return C
 
 

@@ -212,13 +212,22 @@ def test_aby3_relu_chain_parity(gpu, orc, n, fused, monkeypatch):
         Xs = pr.aby3_share(w, X, n)
         Gs, Ps = pr.aby3_add_prepare(w, Xs)
         Zb = pr.aby3_msb(w, Gs, Ps)
+        pops = [list(d) for d in w.pops]
         C = pr.aby3_bit_inject(w, Xs, Zb)
-        res.append((w, Zb, C))
+        # the same call again with the minuend: the GPU's post segment subtracts in the same pass
+        # (mpcx_aby3_bit_inject_p*_post_sub), the oracle runs its post segment and then ring_sub
+        w2 = pr.World(be, record=False)
+        w2.pops = pops
+        R = pr.aby3_bit_inject(w2, Xs, Zb, minuend=Xs)
+        res.append((w, Zb, C, R, Xs))
     same_logs(res[0][0], res[1][0])
     for j in range(3):
         for i in range(2):
             assert np.array_equal(res[0][1][j][i], res[1][1][j][i])
             assert np.array_equal(res[0][2][j][i], res[1][2][j][i])
+            assert np.array_equal(res[0][3][j][i], res[1][3][j][i])
+            assert np.array_equal(res[0][3][j][i], orc.ring_sub(res[1][4][j][i], res[1][2][j][i]))
+    assert np.array_equal(pr.aby3_reveal(res[0][0], res[0][3])[0], np.maximum(X, 0))
     w = res[0][0]
     assert np.array_equal(pr.aby3_reveal_bools(w, res[0][1])[0], (X < 0).astype(np.int8))
     assert np.array_equal(pr.aby3_reveal(w, res[0][2])[0], X * (X < 0))
