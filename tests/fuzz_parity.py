@@ -58,7 +58,7 @@ def case_aby3_relu(rng, gpu, orc):
     wo = pr.World(orc)
     want = aby3_relu(wo, x)
     ranges = random_ranges(rng, n)
-    got, log = run_in_ranges(gpu, aby3_relu, x, ranges, halves=2)
+    got, log = run_in_ranges(gpu, aby3_relu, x, ranges, halves=4)
     same_logs(log, wo.log)
     for j in range(3):
         assert np.array_equal(got[j], want[j]), ("aby3 relu", n, ranges, j)

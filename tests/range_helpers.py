@@ -33,12 +33,19 @@ def same_logs(got, want):
 
 
 def aby3_relu(w, x):
-    """test/test_ABY3.cpp:196-214: share -> add_prepare -> msb -> bit_inject; returns the shares of x * msb(x)."""
+    """test/test_ABY3.cpp:196-214: share -> add_prepare -> msb -> bit_inject; returns, per party, both shares of x * msb(x)
+    followed by both shares of x - x * msb(x)."""
     Xs = pr.aby3_share(w, x, x.size)
     Gs, Ps = pr.aby3_add_prepare(w, Xs)
     Zb = pr.aby3_msb(w, Gs, Ps)
+    pops = [list(p) for p in w.pops]
     C = pr.aby3_bit_inject(w, Xs, Zb)
-    return [np.concatenate([np.asarray(c[0]), np.asarray(c[1])]) for c in C]
+    # and once more with the minuend (x - x * msb(x), the post segment and the subtraction in one call where the
+    # backend has it), from the same stream positions and without logging the messages a second time
+    w2 = pr.World(w.be, record=False, n_total=w.n_total, i0=w.i0)
+    w2.pops = pops
+    R = pr.aby3_bit_inject(w2, Xs, Zb, minuend=Xs)
+    return [np.concatenate([np.asarray(c[0]), np.asarray(c[1]), np.asarray(r[0]), np.asarray(r[1])]) for c, r in zip(C, R)]
 
 
 def snn_msb(w, a):

@@ -24,13 +24,15 @@ def test_aby3_relu_chain_in_ranges(gpu, orc, ranges):
     x = prg_pops(21, 0, 5000)
     wo = pr.World(orc)
     want = aby3_relu(wo, x)
-    got, log = run_in_ranges(gpu, aby3_relu, x, ranges, halves=2)
+    got, log = run_in_ranges(gpu, aby3_relu, x, ranges, halves=4)
     same_logs(log, wo.log)
     for j in range(3):
         assert np.array_equal(got[j], want[j]), f"party {j}"
     n = x.size
     prod = (want[0][:n].view(np.uint64) + want[1][:n].view(np.uint64) + want[2][:n].view(np.uint64)).view(np.int64)
     assert np.array_equal(prod, np.where(x < 0, x, 0))
+    relu = sum(want[j][2 * n:3 * n].view(np.uint64) for j in range(3)).view(np.int64)
+    assert np.array_equal(relu, np.maximum(x, 0))
 
 
 @pytest.mark.parametrize("ranges", RANGES)
