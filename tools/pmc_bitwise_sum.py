@@ -17,6 +17,9 @@ ALGO = {
     "bi_sender_pre_kernel": ("8 (or 16) + 2 B in, 40 B out, 5 x 0.375 B/word of checkpoints", 54),
     "bi_helper_pre_kernel": ("2 B in, 16 B out", 20),
     "msb_last_kernel": ("2 B message + 2 B backup + bits in, 2 B out", 6.4),
+    "bi_post_kernel": ("with the ReLU minuend, averaged over the three parties: messages and select bytes 25 / 25 / 50 B "
+                       "+ 16 B minuend in, 16 B out (57, 57, 82 B)", 196 / 3),
+    "beaver_deal_vec_kernel": ("6 x 8 B out, 12 stream words x 0.375 B of checkpoints in", 52.5),
 }
 MSB = ["msb_round_pre_kernel", "msb_round_mid_kernel", "msb_round_post_kernel"]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
