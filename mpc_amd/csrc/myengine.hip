@@ -54,6 +54,83 @@ inline int buff(mpcx_ctx *ctx, u64 seed, u64 first, u64 count, u64 *ints, i8 *bo
     return prg_fill_words(ctx, seed, 0, 2 * first, count, 2, (i64 *)ints, bools);
 }
 
+// The dealer's segment of bit_inject (MyEngine.cpp:705-745) in one pass, nothing staged in memory.  For element e of
+// the call: (U_j, B_j) = (int_buff, bool_buff)[i0 + e] of the stream shared with party j (:711-712), b = B_0 ^ B_1,
+// u = U_0 + U_1 (:717-718); the four first shares V_0, W_0, S_0, T_0 are int_buff[s n_total + i0 + e], s = 0..3, of the
+// self stream (:730-739) and the second shares are b u - V_0, (1 ^ b) u - W_0, B_0 B_1 - S_0, B_0 (1 ^ B_1) - T_0.
+// A lane owns 32 consecutive elements (64 stream words, one checkpoint run per generator), works in windows of 16
+// elements, and hands one output array of a window at a time to the wavefront through LDS, which stores it in memory
+// order (128-byte runs).
+struct MyDealArgs {
+    const PrgCk *ck0, *ck1, *ckS;
+    u64 t0, tS[4]; // stream word of element 0 of the call in the pair streams / in the four self-stream sections
+    u64 *first[4], *second[4]; // V W S T
+    u64 n;
+};
+__global__ __launch_bounds__(256) void my_bi_deal_kernel(MyDealArgs P) {
+    constexpr u32 EPL = 32, WIN = 16, PITCH = WIN + 1;
+    __shared__ u64 tile[256 * PITCH];
+    const u32 tid = threadIdx.x;
+    const u64 lane0 = (u64)blockIdx.x * 256;
+    const u64 e0 = (lane0 + tid) * EPL;
+    const bool active = e0 < P.n;
+    PrgCursor g0, g1, gs[4];
+    g0.open(P.ck0, P.t0 + 2 * e0, active);
+    g1.open(P.ck1, P.t0 + 2 * e0, active);
+#pragma unroll
+    for (u32 q = 0; q < 4; q++) gs[q].open(P.ckS, P.tS[q] + 2 * e0, active);
+    u64 *row_tile = tile + tid * PITCH;
+    // the wavefront stores the window its lanes have parked in the tile at dst[element]
+    auto flush = [&](u64 *__restrict__ dst, u32 win) {
+        prg_wave_sync();
+#pragma unroll 4
+        for (u32 j = 0; j < WIN; j++) {
+            const u32 idx = j * 64 + (tid & 63);
+            const u32 row = (tid & ~63u) + idx / WIN, col = idx % WIN;
+            const u64 e = (lane0 + row) * EPL + win * WIN + col;
+            if (e < P.n) dst[e] = tile[row * PITCH + col];
+        }
+        prg_wave_sync();
+    };
+#pragma unroll 1
+    for (u32 win = 0; win < EPL / WIN; win++) {
+        u64 u[WIN];
+        u32 b0 = 0, b1 = 0;
+#pragma unroll
+        for (u32 k = 0; k < WIN; k++) {
+            u[k] = g0.take();
+            b0 |= (u32)(g0.take() & 1) << k;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (u32 k = 0; k < WIN; k++) {
+            u[k] += g1.take();
+            b1 |= (u32)(g1.take() & 1) << k;
+        }
+        // the bit that multiplies u (sections 0, 1) or stands alone (sections 2, 3), per element of the window
+        const u32 sel[4] = {b0 ^ b1, ~(b0 ^ b1), b0 & b1, b0 & ~b1};
+#pragma unroll
+        for (u32 q = 0; q < 4; q++) {
+            // the sections' generators are independent: the fences keep the scheduler from running them side by side
+            __builtin_amdgcn_sched_barrier(0);
+            u64 y[WIN];
+#pragma unroll
+            for (u32 k = 0; k < WIN; k++) {
+                const u64 x = gs[q].take();
+                (void)gs[q].next();
+                const u64 bit = (sel[q] >> k) & 1;
+                row_tile[k] = x;
+                y[k] = (q < 2 ? bit * u[k] : bit) - x;
+            }
+            flush(P.first[q], win);
+#pragma unroll
+            for (u32 k = 0; k < WIN; k++) row_tile[k] = y[k];
+            flush(P.second[q], win);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 } // namespace
 
 extern "C" {
@@ -223,31 +300,30 @@ int mpcx_my_bit_inject_dealer(mpcx_ctx *ctx, uint64_t seed0, uint64_t seed1, uin
     if (n == 0) return 0;
     MPCX_REQUIRE(V0 && W0 && S0 && T0 && V1 && W1 && S1 && T1, "mpcx_my_bit_inject_dealer: NULL pointer");
     MPCX_REQUIRE(i0 + n <= n_total, "mpcx_my_bit_inject_dealer: range outside the vector");
-    Tmp t(ctx);
-    MPCX_TRY(t.get(18 * n + 64));
-    u64 *U0 = (u64 *)t.p, *U1 = U0 + n;
-    i8 *B0 = (i8 *)(U1 + n), *B1 = B0 + n;
-    MPCX_TRY(buff(ctx, seed0, i0, n, U0, B0)); // :711-712
-    MPCX_TRY(buff(ctx, seed1, i0, n, U1, B1));
-    MPCX_TRY(buff(ctx, seedS, i0, n, (u64 *)V0));               // :730
-    MPCX_TRY(buff(ctx, seedS, n_total + i0, n, (u64 *)W0));     // :733
-    MPCX_TRY(buff(ctx, seedS, 2 * n_total + i0, n, (u64 *)S0)); // :736
-    MPCX_TRY(buff(ctx, seedS, 3 * n_total + i0, n, (u64 *)T0)); // :739
-    return ew_launch(ctx, n, [=] __device__(u64 i) {
-        const i8 b = (i8)(B0[i] ^ B1[i]); // :717
-        const u64 u = U0[i] + U1[i];      // :718
-        V1[i] = (i64)((u64)(i64)b * u - (u64)V0[i]);
-        W1[i] = (i64)((u64)(i64)(1 ^ b) * u - (u64)W0[i]);
-        S1[i] = (i64)((u64)(i64)(B0[i] * B1[i]) - (u64)S0[i]);
-        T1[i] = (i64)((u64)(i64)(B0[i] * (1 ^ B1[i])) - (u64)T0[i]);
-    });
+    MyDealArgs P;
+    MPCX_TRY(mpcx_prg_table(ctx, seed0, 0, 2 * (i0 + n) + PRG_CK, &P.ck0));
+    MPCX_TRY(mpcx_prg_table(ctx, seed1, 0, 2 * (i0 + n) + PRG_CK, &P.ck1));
+    MPCX_TRY(mpcx_prg_table(ctx, seedS, 0, 2 * (3 * n_total + i0 + n) + PRG_CK, &P.ckS));
+    P.t0 = 2 * i0;
+    int64_t *firsts[4] = {V0, W0, S0, T0}, *seconds[4] = {V1, W1, S1, T1};
+    for (int q = 0; q < 4; q++) {
+        P.tS[q] = 2 * ((u64)q * n_total + i0);
+        P.first[q] = (u64 *)firsts[q], P.second[q] = (u64 *)seconds[q];
+    }
+    P.n = n;
+    const u64 grid = ceil_div(ceil_div(n, 32), 256);
+    MPCX_REQUIRE(grid < (1ull << 31), "mpcx_my_bit_inject_dealer: range too large for one launch");
+    ProfScope ps(ctx, PROF_PRG);
+    hipLaunchKernelGGL(my_bi_deal_kernel, dim3((u32)grid), dim3(256), 0, ctx->stream, P);
+    MPCX_LAUNCH_CHECK();
+    return 0;
 }
 int mpcx_my_bit_inject_party_pre(mpcx_ctx *ctx, const int64_t *X, const int8_t *A, uint64_t seed2, uint64_t i0, uint64_t n,
                                  int64_t *y_out, int8_t *c_out) {
     if (n == 0) return 0;
     MPCX_REQUIRE(X && A && y_out && c_out, "mpcx_my_bit_inject_party_pre: NULL pointer");
     const u64 first[1] = {i0}; // U = int_buff[i0 + i], B = bool_buff[i0 + i] (:610-611)
-    return prg_buff_map<1, MyPair>(
+    return prg_buff_map<1, MyPair, 8>(
         ctx, seed2, first, n, [] __device__(const u64(&w)[1], u32 b) { return MyPair{w[0], (u64)b}; },
         [=] __device__(u64 i, MyPair ub) {
             y_out[i] = (i64)((u64)X[i] - ub.a);   // :619

@@ -44,6 +44,13 @@ struct PrgCursor {
         for (u32 i = 0; i < (u32)(t % PRG_CK); i++) prv_step(s, l, h);
     }
     __device__ u64 next() { return prv_step(s, l, h); }
+    // the same word, formed on the spot: left to itself the compiler may carry lcg and the rotated seed of every step of
+    // an unrolled run along and xor them only where the word is used, four registers per step instead of two
+    __device__ u64 take() {
+        u64 w = prv_step(s, l, h);
+        asm volatile("" : "+v"(w));
+        return w;
+    }
 };
 
 // PRG_CK / 2 bytes (uint16)int_buff % 67 from one checkpoint, packed four to a word
@@ -144,12 +151,14 @@ int prg_map2(mpcx_ctx *ctx, u64 seedA, u64 tA, u64 seedB, u64 tB, u64 count, G g
 // (utils/PRgenerator.cpp:27-32, extended to every i).  Element i of the call reads int_buff[first[s] + i] of up to three
 // sections s of ONE generator (and bool_buff[first[0] + i]); g folds them, in the producing lane, into a value V
 // (trivially copyable, a multiple of 8 bytes) and f(i, V) runs in memory order.  A lane owns PRG_CK / 2 consecutive
-// elements; every 8 elements the wavefront visits its 64 x 8 values with consecutive lanes on consecutive elements.
-template <int NS, class V, class G, class F>
+// elements; every 16 (or 8) elements the wavefront visits its 64 x 16 values with consecutive lanes on consecutive elements.
+// Elements per visit: 16 (128-byte runs of 8-byte words) while the tile stays near 64 KiB, else 8; CHV overrides it
+// (measured per consumer: a light consumer of a two-word value prefers the smaller tile and twice the workgroups).
+template <int NS, class V, u32 CHV, class G, class F>
 __global__ __launch_bounds__(256) void prg_buff_map_kernel(const PrgCk *__restrict__ ck, u64 f0, u64 f1, u64 f2, u64 count,
                                                            G g, F f) {
     static_assert(sizeof(V) % 8 == 0 && NS >= 1 && NS <= 3, "value layout");
-    constexpr u32 VW = sizeof(V) / 8, EPL = PRG_CK / 2, CH = 8, PITCH = CH * VW + 1;
+    constexpr u32 VW = sizeof(V) / 8, EPL = PRG_CK / 2, CH = CHV ? CHV : (VW <= 2 ? 16 : 8), PITCH = CH * VW + 1;
     __shared__ u64 tile[256 * PITCH];
     const u32 tid = threadIdx.x;
     const u64 blk_r0 = (u64)blockIdx.x * 256;
@@ -193,7 +202,7 @@ __global__ __launch_bounds__(256) void prg_buff_map_kernel(const PrgCk *__restri
     }
 }
 
-template <int NS, class V, class G, class F>
+template <int NS, class V, u32 CHV = 0, class G, class F>
 int prg_buff_map(mpcx_ctx *ctx, u64 seed, const u64 (&first)[NS], u64 count, G g, F f) {
     if (count == 0) return 0;
     u64 top = 0;
@@ -203,7 +212,7 @@ int prg_buff_map(mpcx_ctx *ctx, u64 seed, const u64 (&first)[NS], u64 count, G g
     const u64 grid = ceil_div(ceil_div(count, PRG_CK / 2), 256);
     MPCX_REQUIRE(grid < (1ull << 31), "prg map: range too large for one launch");
     ProfScope ps(ctx, PROF_PRG);
-    hipLaunchKernelGGL((prg_buff_map_kernel<NS, V, G, F>), dim3((u32)grid), dim3(256), 0, ctx->stream, ck, first[0],
+    hipLaunchKernelGGL((prg_buff_map_kernel<NS, V, CHV, G, F>), dim3((u32)grid), dim3(256), 0, ctx->stream, ck, first[0],
                        NS > 1 ? first[NS > 1 ? 1 : 0] : 0, NS > 2 ? first[NS > 2 ? 2 : 0] : 0, count, g, f);
     MPCX_LAUNCH_CHECK();
     return 0;

@@ -347,9 +347,9 @@ __global__ __launch_bounds__(256) void beaver_deal_vec_kernel(DealVecArgs P) {
         u64 a[WIN], b[WIN], c[WIN];
 #pragma unroll
         for (u32 k = 0; k < WIN; k++) { // the odd stream words are the generator's bool_buff entries
-            a[k] = g0.next(), (void)g0.next();
-            b[k] = g0.next(), (void)g0.next();
-            c[k] = g0.next(), (void)g0.next();
+            a[k] = g0.take(), (void)g0.next();
+            b[k] = g0.take(), (void)g0.next();
+            c[k] = g0.take(), (void)g0.next();
         }
         flush(P.out[0], win, a);
         flush(P.out[1], win, b);
@@ -357,9 +357,9 @@ __global__ __launch_bounds__(256) void beaver_deal_vec_kernel(DealVecArgs P) {
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (u32 k = 0; k < WIN; k++) {
-            const u64 a1 = g1.next();
+            const u64 a1 = g1.take();
             (void)g1.next();
-            const u64 b1 = g1.next();
+            const u64 b1 = g1.take();
             for (u32 q = 0; q < 3; q++) (void)g1.next(); // bool, the unused C word of section 1, bool
             c[k] = (a[k] + a1) * (b[k] + b1) - c[k];
             a[k] = a1, b[k] = b1;
