@@ -55,10 +55,14 @@ int mpcx_d2h(mpcx_ctx *ctx, void *dst, const void *src, uint64_t bytes);
 int mpcx_d2d(mpcx_ctx *ctx, void *dst, const void *src, uint64_t bytes);
 /* mpcx_h2d / mpcx_d2h return when the copy is complete; host memory may be pageable (the std::string payloads of
  * VirtuleMessenger::send_and_recv, utils/VirtuleMessenger.hpp:14).  Transfers of 4 MiB and more are pipelined through
- * two pinned staging buffers of the context, DMA on one chunk while host threads (MPCX_COPY_THREADS, default 4) copy
+ * two pinned staging buffers of the context, DMA on one chunk while host threads (MPCX_COPY_THREADS; default: half the hardware threads, 4 to 16) copy
  * the other.  mpcx_host_copy is that multi-threaded memcpy by itself, for messengers that move payloads between
  * host buffers (utils/SocketMessenger.cpp:142-164 does it through the kernel's socket buffers). */
 int mpcx_host_copy(void *dst, const void *src, uint64_t bytes);
+/* dst (cols x rows, row-major) = the transpose of src (rows x cols, row-major), 8-byte words, host memory, on the same
+ * threads: the conversion between the row-major wire order of matrix2string / string2matrix (utils/util.hpp:19-52) and
+ * Eigen's column-major storage.  dst and src must not overlap.  Needs no context and no GPU. */
+int mpcx_host_transpose64(void *dst, const void *src, uint64_t rows, uint64_t cols);
 /* per-kernel device timing with HIP events recorded on the context's stream: mpcx_profile(ctx,1) starts
  * (and clears) the collection, mpcx_profile_read sums the elapsed time of every launch of one kernel
  * family since then: "limb_gemm", "split_limbs", "prg_fill", "pc_party", "pc_helper",

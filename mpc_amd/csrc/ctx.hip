@@ -23,8 +23,10 @@ struct CopyPool {
     std::deque<std::function<void()>> jobs;
     unsigned threads = 0;
     CopyPool() {
+        // default: half the hardware threads, between 4 and 16 (the callers copy and transpose alongside the pool)
         const char *e = getenv("MPCX_COPY_THREADS");
-        long n = e ? atol(e) : 4;
+        long n = e ? atol(e) : (long)(std::thread::hardware_concurrency() / 2);
+        if (!e) n = n < 4 ? 4 : n > 16 ? 16 : n;
         threads = (unsigned)(n < 0 ? 0 : n > 32 ? 32 : n);
         for (unsigned i = 0; i < threads; i++)
             std::thread([this] {
@@ -87,16 +89,13 @@ struct CopyTimer {
 };
 } // namespace
 
-void mpcx_parallel_memcpy(void *dst, const void *src, u64 bytes) {
+// fn(k) for k in [0, pieces): piece 0 on the calling thread, the others on the pool
+template <class F> static void pool_run(u64 pieces, F fn) {
     CopyPool &P = copy_pool();
-    const u64 piece_min = 1ull << 20;
-    if (P.threads == 0 || bytes < 2 * piece_min) {
-        memcpy(dst, src, bytes);
+    if (pieces <= 1 || P.threads == 0) {
+        for (u64 k = 0; k < pieces; k++) fn(k);
         return;
     }
-    u64 pieces = bytes / piece_min;
-    if (pieces > P.threads + 1) pieces = P.threads + 1; // the caller copies a piece itself
-    const u64 per = ((bytes + pieces - 1) / pieces + 63) & ~63ull;
     struct Latch {
         std::mutex mu;
         std::condition_variable cv;
@@ -107,19 +106,45 @@ void mpcx_parallel_memcpy(void *dst, const void *src, u64 bytes) {
     latch->left = pieces - 1;
     {
         std::lock_guard<std::mutex> lk(P.mu);
-        for (u64 k = 1; k < pieces; k++) {
-            const u64 off = k * per, len = off >= bytes ? 0 : (bytes - off < per ? bytes - off : per);
+        for (u64 k = 1; k < pieces; k++)
             P.jobs.emplace_back([=] {
-                if (len) memcpy((char *)dst + off, (const char *)src + off, len);
+                fn(k);
                 std::lock_guard<std::mutex> g(latch->mu);
                 if (--latch->left == 0) latch->cv.notify_one();
             });
-        }
     }
     P.cv.notify_all();
-    memcpy(dst, src, per < bytes ? per : bytes);
+    fn(0);
     std::unique_lock<std::mutex> lk(latch->mu);
     latch->cv.wait(lk, [&] { return latch->left == 0; });
+}
+
+void mpcx_parallel_memcpy(void *dst, const void *src, u64 bytes) {
+    CopyPool &P = copy_pool();
+    const u64 piece_min = 1ull << 20;
+    if (P.threads == 0 || bytes < 2 * piece_min) {
+        memcpy(dst, src, bytes);
+        return;
+    }
+    u64 pieces = bytes / piece_min;
+    if (pieces > P.threads + 1) pieces = P.threads + 1; // the caller copies a piece itself
+    const u64 per = ((bytes + pieces - 1) / pieces + 63) & ~63ull;
+    pool_run(pieces, [=](u64 k) {
+        const u64 off = k * per;
+        if (off < bytes) memcpy((char *)dst + off, (const char *)src + off, bytes - off < per ? bytes - off : per);
+    });
+}
+
+// dst (C x R, row-major) = transpose of src (R x C, row-major), 8-byte words, in 32 x 32 tiles so that neither side is
+// walked with a large stride; bands of destination rows go to the pool's threads
+static void transpose64_band(u64 *dst, const u64 *src, u64 R, u64 C, u64 c_lo, u64 c_hi) {
+    const u64 T = 32;
+    for (u64 c0 = c_lo; c0 < c_hi; c0 += T)
+        for (u64 r0 = 0; r0 < R; r0 += T) {
+            const u64 c1 = c0 + T < c_hi ? c0 + T : c_hi, r1 = r0 + T < R ? r0 + T : R;
+            for (u64 c = c0; c < c1; c++)
+                for (u64 r = r0; r < r1; r++) dst[c * R + r] = src[r * C + c];
+        }
 }
 
 static thread_local std::string g_init_err;
@@ -356,6 +381,20 @@ int mpcx_d2h(mpcx_ctx *ctx, void *dst, const void *src, uint64_t bytes) {
 int mpcx_host_copy(void *dst, const void *src, uint64_t bytes) {
     CopyTimer timer(2, bytes);
     if (bytes) mpcx_parallel_memcpy(dst, src, bytes);
+    return 0;
+}
+int mpcx_host_transpose64(void *dst, const void *src, uint64_t rows, uint64_t cols) {
+    if (!rows || !cols) return 0;
+    if (!dst || !src || dst == src) return 1;
+    CopyTimer timer(2, 8 * rows * cols);
+    CopyPool &P = copy_pool();
+    u64 pieces = rows * cols < (1ull << 16) ? 1 : P.threads + 1;
+    const u64 band = ((cols + pieces - 1) / pieces + 31) & ~31ull; // whole tiles
+    pieces = (cols + band - 1) / band;
+    pool_run(pieces, [=](u64 k) {
+        const u64 lo = k * band, hi = lo + band < cols ? lo + band : cols;
+        if (lo < hi) transpose64_band((u64 *)dst, (const u64 *)src, rows, cols, lo, hi);
+    });
     return 0;
 }
 int mpcx_d2d(mpcx_ctx *ctx, void *dst, const void *src, uint64_t bytes) {

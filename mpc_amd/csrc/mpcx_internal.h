@@ -67,7 +67,7 @@ struct mpcx_ctx {
 };
 
 int mpcx_fail(mpcx_ctx *ctx, const char *fmt, ...);
-// memcpy cut into pieces moved by the library's pool of host threads (MPCX_COPY_THREADS, default 4) and the caller
+// memcpy cut into pieces moved by the library's pool of host threads (MPCX_COPY_THREADS; default half the hardware threads, 4 to 16) and the caller
 void mpcx_parallel_memcpy(void *dst, const void *src, u64 bytes);
 // scratch of at least `bytes`, 256-byte aligned, valid until the next mpcx_ws call on this context
 int mpcx_ws(mpcx_ctx *ctx, u64 bytes, void **out);

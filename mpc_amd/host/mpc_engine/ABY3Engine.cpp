@@ -328,16 +328,30 @@ void ABY3Engine::matrix_mul(const array<MatrixXl, 2> &Xj, const array<MatrixXl, 
         }
     } else {
         Dev<int64_t> z(gpu, rows * cols);
+        std::unique_ptr<mpcgpu::Span> up(new mpcgpu::Span("matrix_mul: upload"));
         Dev<int64_t> x0(gpu, Xj[0].data(), rows * lens), x1(gpu, Xj[1].data(), rows * lens);
         Dev<int64_t> y0(gpu, Yj[0].data(), lens * cols), y1(gpu, Yj[1].data(), lens * cols);
+        up.reset();
         // Eigen stores column-major (layout 1); the result comes back row-major = the wire order
-        GPU_OK(gpu, mpcx_aby3_matmul_local(gpu, x0, x1, y0, y1, rows, lens, cols, 1, prgs[pe.next].init_seed,
-                                           prgs[pe.next].pops, prgs[pe.prev].init_seed, prgs[pe.prev].pops, z));
+        {
+            mpcgpu::Span s2("matrix_mul: product");
+            GPU_OK(gpu, mpcx_aby3_matmul_local(gpu, x0, x1, y0, y1, rows, lens, cols, 1, prgs[pe.next].init_seed,
+                                               prgs[pe.next].pops, prgs[pe.prev].init_seed, prgs[pe.prev].pops, z));
+            if (mpcgpu::Span::on()) GPU_OK(gpu, mpcx_sync(gpu)); // so that the span is the product's own time
+        }
+        mpcgpu::Span s3("matrix_mul: download");
         z.to_string(message_send[pe.prev]);
     }
-    prgs[pe.next].advance(gpu, rows * cols);
-    prgs[pe.prev].advance(gpu, rows * cols);
-    messenger->send_and_recv(message_send, message_recv);
+    {
+        mpcgpu::Span s4("matrix_mul: advance");
+        prgs[pe.next].advance(gpu, rows * cols);
+        prgs[pe.prev].advance(gpu, rows * cols);
+    }
+    {
+        mpcgpu::Span s5("matrix_mul: round");
+        messenger->send_and_recv(message_send, message_recv);
+    }
+    mpcgpu::Span s6("matrix_mul: to matrices");
     Zj[0].resize(rows, cols);
     Zj[1].resize(rows, cols);
     string2matrix(message_send[pe.prev], Zj[0]);

@@ -5,6 +5,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <chrono>
 #include <memory>
 #include <string>
 #include <vector>
@@ -42,6 +43,27 @@ template <class F> struct AtExit {
     ~AtExit() { f(); }
 };
 #endif
+
+// MPCX_ENGINE_TRACE=1: wall time of the steps of an engine method on stderr (one line per step and call)
+struct Span {
+    const char *what;
+    std::chrono::steady_clock::time_point t0;
+    static bool on() {
+        static const bool v = [] {
+            const char *e = getenv("MPCX_ENGINE_TRACE");
+            return e && atoi(e) != 0;
+        }();
+        return v;
+    }
+    explicit Span(const char *w) : what(w) {
+        if (on()) t0 = std::chrono::steady_clock::now();
+    }
+    ~Span() {
+        if (on())
+            fprintf(stderr, "[engine] %-28s %9.3f ms\n", what,
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    }
+};
 
 inline mpcx_ctx *open_context() {
     mpcx_ctx *ctx = nullptr;

@@ -20,25 +20,30 @@ using std::string;
 using std::vector;
 
 // The wire order is row-major, the matrices are stored column-major: both directions are a transposition, done
-// in 32 x 32 tiles so that neither side is walked with a large stride.
-static inline void cm_to_rm(const int64_t *cm, int64_t *rm, size_t rows, size_t cols) {
+// in 32 x 32 tiles so that neither side is walked with a large stride.  Large matrices go to the GPU library's
+// host threads when the program is linked with it (a 4096 x 4096 matrix takes one core 70-100 ms).
+extern "C" int mpcx_host_transpose64(void *dst, const void *src, uint64_t rows, uint64_t cols) __attribute__((weak));
+// dst (C x R, row-major) = transpose of src (R x C, row-major)
+static inline void transpose_words(const int64_t *src, int64_t *dst, size_t R, size_t C) {
+    if (mpcx_host_transpose64 && R * C >= (size_t)1 << 16 && mpcx_host_transpose64(dst, src, R, C) == 0) return;
     const size_t T = 32;
-    for (size_t j0 = 0; j0 < cols; j0 += T)
-        for (size_t i0 = 0; i0 < rows; i0 += T) {
-            const size_t j1 = j0 + T < cols ? j0 + T : cols, i1 = i0 + T < rows ? i0 + T : rows;
-            for (size_t j = j0; j < j1; j++)
-                for (size_t i = i0; i < i1; i++) rm[i * cols + j] = cm[j * rows + i];
+    for (size_t c0 = 0; c0 < C; c0 += T)
+        for (size_t r0 = 0; r0 < R; r0 += T) {
+            const size_t c1 = c0 + T < C ? c0 + T : C, r1 = r0 + T < R ? r0 + T : R;
+            for (size_t c = c0; c < c1; c++)
+                for (size_t r = r0; r < r1; r++) dst[c * R + r] = src[r * C + c];
         }
 }
-static inline void rm_to_cm(const int64_t *rm, int64_t *cm, size_t rows, size_t cols) {
-    const size_t T = 32;
-    for (size_t j0 = 0; j0 < cols; j0 += T)
-        for (size_t i0 = 0; i0 < rows; i0 += T) {
-            const size_t j1 = j0 + T < cols ? j0 + T : cols, i1 = i0 + T < rows ? i0 + T : rows;
-            for (size_t j = j0; j < j1; j++)
-                for (size_t i = i0; i < i1; i++) cm[j * rows + i] = rm[i * cols + j];
-        }
+// payload copies: the library's multi-threaded memcpy from 4 MiB on when the program is linked with it
+extern "C" int mpcx_host_copy(void *dst, const void *src, uint64_t bytes) __attribute__((weak));
+static inline void copy_bytes(void *dst, const void *src, size_t bytes) {
+    if (!bytes) return;
+    if (mpcx_host_copy && bytes >= ((size_t)4 << 20) && mpcx_host_copy(dst, src, bytes) == 0) return;
+    memcpy(dst, src, bytes);
 }
+// a column-major rows x cols matrix is the row-major cols x rows matrix of its transpose
+static inline void cm_to_rm(const int64_t *cm, int64_t *rm, size_t rows, size_t cols) { transpose_words(cm, rm, cols, rows); }
+static inline void rm_to_cm(const int64_t *rm, int64_t *cm, size_t rows, size_t cols) { transpose_words(rm, cm, rows, cols); }
 static inline void matrix2string(const MatrixXl &input, string &output) {
     const size_t rows = input.rows(), cols = input.cols();
     output.resize(rows * cols * sizeof(int64_t));
@@ -55,7 +60,7 @@ static inline void vector2string(const vector<int64_t> &input, string &output) {
 static inline void string2vector(const string &input, vector<int64_t> &output) {
     assert(input.size() % sizeof(int64_t) == 0);
     output.resize(input.size() / sizeof(int64_t));
-    if (!input.empty()) memcpy(output.data(), input.data(), input.size());
+    copy_bytes(output.data(), input.data(), input.size());
 }
 static inline void vecZpshare2string(const vector<zpshare> &input, string &output) {
     output.assign((const char *)input.data(), input.size() * sizeof(zpshare));
@@ -63,7 +68,7 @@ static inline void vecZpshare2string(const vector<zpshare> &input, string &outpu
 static inline void string2vecZpshare(const string &input, vector<zpshare> &output) {
     assert(input.size() % sizeof(zpshare) == 0);
     output.resize(input.size() / sizeof(zpshare));
-    if (!input.empty()) memcpy(output.data(), input.data(), input.size());
+    copy_bytes(output.data(), input.data(), input.size());
 }
 static inline void matrix2vector(const MatrixXl &input, vector<int64_t> &output) {
     const size_t rows = input.rows(), cols = input.cols();
@@ -76,12 +81,13 @@ static inline void vector2matrix(const vector<int64_t> &input, MatrixXl &output)
     if (rows && cols) rm_to_cm(input.data(), output.data(), rows, cols);
 }
 static inline void vecI642string(const VecI64 &input, string &output) {
-    output.assign((const char *)input.data(), input.size() * sizeof(int64_t));
+    output.resize(input.size() * sizeof(int64_t));
+    if (input.size()) copy_bytes(&output[0], input.data(), output.size());
 }
 static inline void string2vecI64(const string &input, VecI64 &output) {
     assert(input.size() % sizeof(int64_t) == 0);
     output.resize(input.size() / sizeof(int64_t));
-    if (!input.empty()) memcpy(output.data(), input.data(), input.size());
+    copy_bytes(output.data(), input.data(), input.size());
 }
 static inline void vecI642matrix(const VecI64 &input, MatrixXl &output) {
     const size_t rows = output.rows(), cols = output.cols();

@@ -44,6 +44,22 @@ def test_in_process_messenger_and_host_copy():
     assert r.returncode == 0 and "all checks passed" in r.stdout, r.stdout + r.stderr
 
 
+@pytest.mark.parametrize("rows,cols", [(1, 1), (3, 5), (31, 33), (257, 256), (1000, 777), (2048, 1031)])
+def test_host_transpose_matches_numpy(rows, cols):
+    """mpcx_host_transpose64 (the codecs' row-major <-> column-major conversion; needs no GPU): single-threaded below
+    2^16 words, in bands over the library's host threads above; ragged shapes leave partial tiles on both sides."""
+    import ctypes
+    import numpy as np
+    import mpc_amd
+    lib = mpc_amd.load_library()
+    src = np.random.default_rng(rows * cols).integers(-2 ** 63, 2 ** 63, (rows, cols), dtype=np.int64)
+    dst = np.full((cols, rows), -1, dtype=np.int64)
+    U64 = ctypes.c_uint64
+    assert lib.mpcx_host_transpose64(ctypes.c_void_p(dst.ctypes.data), ctypes.c_void_p(src.ctypes.data), U64(rows), U64(cols)) == 0
+    assert np.array_equal(dst, src.T)
+    assert lib.mpcx_host_transpose64(ctypes.c_void_p(src.ctypes.data), ctypes.c_void_p(src.ctypes.data), U64(rows), U64(cols)) != 0
+
+
 def test_host_headers_keep_the_reference_surface():
     """Same class / method / member names as mpc_engine/ABY3Engine.hpp:24-54 and SecurennEngine.hpp:20-50."""
     a = open(os.path.join(HOST, "mpc_engine", "ABY3Engine.hpp")).read()
