@@ -297,7 +297,9 @@ int mpcx_snn_msbl1_party_finish(mpcx_ctx *ctx, const int64_t *gamma, const int64
  *  party_mid_open      after vector_mul's round 1 (A, B of the triple have arrived): gamma_j, delta_j and the masked
  *                      operands E, F                        (= msbl1_party_mid + beaver_party_open_vecmul)
  *  party_finish        after vector_mul's round 2       (= beaver_party_finish_vecmul + msbl1_party_finish)
- * A is the msb() input a_j itself (not doubled). */
+ * A is the msb() input a_j itself (not doubled).  gamma_out / delta_out of party_mid_open and gamma / delta of
+ * party_finish may both be NULL: party_finish then forms gamma + delta again as (E_own + A) + (F_own + B), which saves
+ * writing and reading the two arrays. */
 int mpcx_snn_msb_party_open(mpcx_ctx *ctx, int party, const int64_t *A, uint64_t n_total, uint64_t i0, uint64_t n,
                             uint64_t seed01, int64_t *x_out);
 int mpcx_snn_msb_party_convert_open(mpcx_ctx *ctx, int party, const int64_t *A, const int64_t *delta_j,

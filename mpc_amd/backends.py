@@ -334,13 +334,21 @@ class GpuBackend:
 
     def snn_msb_party_mid_open(self, party, beta1_j, xlsb_j, beta0, R, A, B):
         n = R.size
+        if not self.snn_msb_keeps_gamma_delta:  # finish forms gamma + delta again from E, F and the triple
+            E, F = self._go("snn_msb_party_mid_open", party, _c(beta1_j, np.int64), _c(xlsb_j, np.int64),
+                            _c(beta0, np.int8), _c(R, np.int64), _c(A, np.int64), _c(B, np.int64), n, None, None,
+                            *[("out", np.int64, n)] * 2)
+            return None, None, E, F
         return self._go("snn_msb_party_mid_open", party, _c(beta1_j, np.int64), _c(xlsb_j, np.int64), _c(beta0, np.int8),
                         _c(R, np.int64), _c(A, np.int64), _c(B, np.int64), n, *[("out", np.int64, n)] * 4)
+
+    snn_msb_keeps_gamma_delta = False
 
     def snn_msb_party_finish(self, party, A, B, C, E_own, F_own, E_peer, F_peer, gamma, delta):
         n = A.size
         return self._go("snn_msb_party_finish", party,
-                        *[_c(x, np.int64) for x in (A, B, C, E_own, F_own, E_peer, F_peer, gamma, delta)], n,
+                        *[_c(x, np.int64) for x in (A, B, C, E_own, F_own, E_peer, F_peer)],
+                        None if gamma is None else _c(gamma, np.int64), None if delta is None else _c(delta, np.int64), n,
                         ("out", np.int64, n))
 
 

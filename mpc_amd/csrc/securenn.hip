@@ -743,7 +743,7 @@ int mpcx_snn_msbl1_helper_deal(mpcx_ctx *ctx, uint64_t n_total, uint64_t i0, uin
         u64 X0, X1, lsb0;
     };
     const u64 first[3] = {i0, n_total + i0, 2 * n_total + i0};
-    MPCX_TRY((prg_buff_map<3, Deal>(
+    MPCX_TRY((prg_buff_map<3, Deal, 16>(
         ctx, seedS, first, n,
         [] __device__(const u64(&w)[3], u32) { return Deal{w[0] % L_1, w[1] % L_1, w[2]}; }, // :911-914, :917
         [=] __device__(u64 i, Deal d) {
@@ -875,15 +875,18 @@ int mpcx_snn_msb_party_mid_open(mpcx_ctx *ctx, int party, const int64_t *beta1_j
                                 const int8_t *beta0, const int64_t *R, const int64_t *A, const int64_t *B, uint64_t n,
                                 int64_t *gamma_out, int64_t *delta_out, int64_t *E, int64_t *F) {
     MPCX_REQUIRE(party == 0 || party == 1, "mpcx_snn_msb_party_mid_open: party %d", party);
-    MPCX_REQUIRE((beta1_j && xlsb_j && beta0 && R && A && B && gamma_out && delta_out && E && F) || n == 0,
-                 "mpcx_snn_msb_party_mid_open: NULL pointer");
+    MPCX_REQUIRE((beta1_j && xlsb_j && beta0 && R && A && B && E && F) || n == 0, "mpcx_snn_msb_party_mid_open: NULL pointer");
+    MPCX_REQUIRE(!gamma_out == !delta_out, "mpcx_snn_msb_party_mid_open: gamma_out and delta_out go together");
     const u64 pid = (u64)party;
+    const bool keep = gamma_out != nullptr; // without them mpcx_snn_msb_party_finish forms gamma = E + A, delta = F + B again
     return ew_launch(ctx, n, [=] __device__(u64 i) {
         const u64 r0 = (u64)R[i] % 2, b0 = (u64)(i64)beta0[i];
         const u64 g = (u64)beta1_j[i] + pid * b0 - 2 * b0 * (u64)beta1_j[i];
         const u64 d = (u64)xlsb_j[i] + pid * r0 - 2 * r0 * (u64)xlsb_j[i];
-        gamma_out[i] = (i64)g;
-        delta_out[i] = (i64)d;
+        if (keep) {
+            gamma_out[i] = (i64)g;
+            delta_out[i] = (i64)d;
+        }
         E[i] = (i64)(g - (u64)A[i]);
         F[i] = (i64)(d - (u64)B[i]);
     });
@@ -893,13 +896,17 @@ int mpcx_snn_msb_party_finish(mpcx_ctx *ctx, int party, const int64_t *A, const 
                               const int64_t *E_own, const int64_t *F_own, const int64_t *E_peer, const int64_t *F_peer,
                               const int64_t *gamma, const int64_t *delta, uint64_t n, int64_t *Bout) {
     MPCX_REQUIRE(party == 0 || party == 1, "mpcx_snn_msb_party_finish: party %d", party);
-    MPCX_REQUIRE((A && B && C && E_own && F_own && E_peer && F_peer && gamma && delta && Bout) || n == 0,
-                 "mpcx_snn_msb_party_finish: NULL pointer");
+    MPCX_REQUIRE((A && B && C && E_own && F_own && E_peer && F_peer && Bout) || n == 0, "mpcx_snn_msb_party_finish: NULL pointer");
+    MPCX_REQUIRE(!gamma == !delta, "mpcx_snn_msb_party_finish: gamma and delta go together");
     const u64 pid = (u64)party;
+    const bool given = gamma != nullptr;
     return ew_launch(ctx, n, [=] __device__(u64 i) {
-        const u64 Ev = (u64)E_own[i] + (u64)E_peer[i], Fv = (u64)F_own[i] + (u64)F_peer[i];
-        const u64 theta = (u64)C[i] + Ev * (u64)B[i] + Fv * (u64)A[i] + Fv * Ev * pid;
-        Bout[i] = (i64)((u64)gamma[i] + (u64)delta[i] - 2 * theta);
+        const u64 a = (u64)A[i], b = (u64)B[i], eo = (u64)E_own[i], fo = (u64)F_own[i];
+        const u64 Ev = eo + (u64)E_peer[i], Fv = fo + (u64)F_peer[i];
+        const u64 theta = (u64)C[i] + Ev * b + Fv * a + Fv * Ev * pid;
+        // gamma + delta: read, or formed again from the party's own masked operands E = gamma - A, F = delta - B
+        const u64 gd = given ? (u64)gamma[i] + (u64)delta[i] : eo + a + fo + b;
+        Bout[i] = (i64)(gd - 2 * theta);
     });
 }
 
