@@ -300,6 +300,31 @@ def test_bit_inject_senders_with_unaligned_inputs(gpu, orc, n):
         assert np.array_equal(o1.to_host(), w1) and np.array_equal(o2.to_host(), w2)
 
 
+@pytest.mark.parametrize("n", [1, 63, 4100])
+def test_bit_inject_post_sub_in_place(gpu, orc, n):
+    """mpcx_aby3_bit_inject_p*_post_sub with the result written over the minuend (R = S, as the header allows): equals
+    the oracle's post segment followed by ring_sub (element ranges of the fused call: tests/test_gpu_ranges.py)."""
+    ctx = gpu.ctx
+    rng = np.random.default_rng(n)
+    nt, i0 = n, 0
+    B0, B1 = (rng.integers(0, 2, n, dtype=np.int8) for _ in range(2))
+    S0, S1 = rnd(rng, n), rnd(rng, n)
+    fa, fb, fc = rnd(rng, 3 * n), rnd(rng, 3 * n), rnd(rng, 3 * n)
+    cases = [("aby3_bit_inject_p0_post_sub", (B0,), (KEY01, 5, KEY20, 9), fa[:2 * n], fb[:n],
+              lambda: orc.aby3_bit_inject_p0_post(B0, KEY01, 5, KEY20, 9, fa[:2 * n], fb[:n])),
+             ("aby3_bit_inject_p1_post_sub", (B1,), (KEY01, 5, KEY12, 9), fa[:2 * n], fb[:n],
+              lambda: orc.aby3_bit_inject_p1_post(B1, KEY01, 5, KEY12, 9, fa[:2 * n], fb[:n])),
+             ("aby3_bit_inject_p2_post_sub", (B0, B1), (KEY20, 5, KEY12, 9), fa, fc,
+              lambda: orc.aby3_bit_inject_p2_post(B0, B1, KEY20, 5, KEY12, 9, fa, fc))]
+    for name, bits, keys, m1, m2, want in cases:
+        C = want()
+        d0, d1 = ctx.to_device(S0), ctx.to_device(S1)
+        ctx.call(name, *[ctx.to_device(b) for b in bits], nt, i0, n, *keys, ctx.to_device(m1), ctx.to_device(m2), d0, d1, d0, d1)
+        ctx.sync()
+        assert np.array_equal(d0.to_host(), orc.ring_sub(S0, C[0])), name
+        assert np.array_equal(d1.to_host(), orc.ring_sub(S1, C[1])), name
+
+
 def test_empty_inputs_are_noops(gpu):
     e = np.zeros(0, dtype=np.int64)
     assert gpu.ring_add(e, e).size == 0
