@@ -393,6 +393,11 @@ int mpcx_group_for_each(mpcx_group *g, uint64_t n, uint64_t granule, mpcx_member
 int mpcx_group_aby3_matmul_local(mpcx_group *g, const int64_t *X0, const int64_t *X1, const int64_t *Y0,
                                  const int64_t *Y1, uint64_t r, uint64_t l, uint64_t c, int layout, uint64_t seed_next,
                                  uint64_t pop_next, uint64_t seed_prev, uint64_t pop_prev, int64_t *Z0);
+/* mpcx_snn_beaver_party_finish_matmul (SecurennEngine.cpp:157-167) over the group.  triple (A | B | C), ef_own and ef_peer
+ * (E | F) are HOST pointers in the wire order of the messages that carry them, Z (r x c, row-major) a host pointer:
+ * every member uploads its rows of A, C and E and all of B and F, and writes its rows of Z into place. */
+int mpcx_group_snn_beaver_party_finish_matmul(mpcx_group *g, int party, const int64_t *triple, const int64_t *ef_own,
+                                              const int64_t *ef_peer, uint64_t r, uint64_t l, uint64_t c, int64_t *Z);
 
 #ifdef __cplusplus
 }

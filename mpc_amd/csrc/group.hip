@@ -228,4 +228,53 @@ int mpcx_group_aby3_matmul_local(mpcx_group *g, const int64_t *X0, const int64_t
     });
 }
 
+
+// SecurennEngine::matrix_mul, parties 0 / 1 after round 2 (SecurennEngine.cpp:157-167): Z = C + E B + A F + party E F with
+// E = E_own + E_peer, F = F_own + F_peer.  The rows of A, C, E (and so of Z) are spread over the members, B and F go to
+// every member; a member's buffers are laid out like the messages of a product with its row count, so that the
+// single-GPU segment runs on them unchanged.
+int mpcx_group_snn_beaver_party_finish_matmul(mpcx_group *g, int party, const int64_t *triple, const int64_t *ef_own,
+                                              const int64_t *ef_peer, uint64_t r, uint64_t l, uint64_t c, int64_t *Z) {
+    if (!g) return group_fail(g, "mpcx_group_snn_beaver_party_finish_matmul: the group is NULL");
+    if (!(triple && ef_own && ef_peer && Z)) return group_fail(g, "mpcx_group_snn_beaver_party_finish_matmul: NULL operand");
+    if (!(r && l && c)) return group_fail(g, "mpcx_group_snn_beaver_party_finish_matmul: empty shape");
+    if (party != 0 && party != 1) return group_fail(g, "mpcx_group_snn_beaver_party_finish_matmul: party %d", party);
+    int members = (int)g->ctx.size();
+    const u64 granule = 128;
+    if (ceil_div(r, granule) < (u64)members) members = (int)ceil_div(r, granule);
+    const u64 na = r * l, nb = l * c;
+    return group_run(g, members, [=](int k) -> int {
+        mpcx_ctx *ctx = g->ctx[k];
+        u64 row0 = 0, rows = 0;
+        mpcx_plan_split(r, members, k, granule, &row0, &rows);
+        if (rows == 0) return 0;
+        const u64 ma = rows * l, mc = rows * c;
+        void *pt = nullptr, *po = nullptr, *pp = nullptr, *pz = nullptr;
+        auto release = [&](int rc) {
+            for (void *p : {pt, po, pp, pz}) (void)mpcx_free(ctx, p);
+            return rc;
+        };
+#define G_TRY(call)                                                                                                    \
+    do {                                                                                                               \
+        if ((call) != 0) return release(1);                                                                            \
+    } while (0)
+        G_TRY(mpcx_malloc(ctx, 8 * (ma + nb + mc), &pt));
+        G_TRY(mpcx_malloc(ctx, 8 * (ma + nb), &po));
+        G_TRY(mpcx_malloc(ctx, 8 * (ma + nb), &pp));
+        G_TRY(mpcx_malloc(ctx, 8 * mc, &pz));
+        i64 *t = (i64 *)pt, *o = (i64 *)po, *q = (i64 *)pp;
+        G_TRY(mpcx_h2d(ctx, t, triple + row0 * l, 8 * ma));                 // A rows
+        G_TRY(mpcx_h2d(ctx, t + ma, triple + na, 8 * nb));                  // B
+        G_TRY(mpcx_h2d(ctx, t + ma + nb, triple + na + nb + row0 * c, 8 * mc)); // C rows
+        G_TRY(mpcx_h2d(ctx, o, ef_own + row0 * l, 8 * ma));
+        G_TRY(mpcx_h2d(ctx, o + ma, ef_own + na, 8 * nb));
+        G_TRY(mpcx_h2d(ctx, q, ef_peer + row0 * l, 8 * ma));
+        G_TRY(mpcx_h2d(ctx, q + ma, ef_peer + na, 8 * nb));
+        G_TRY(mpcx_snn_beaver_party_finish_matmul(ctx, party, t, o, q, rows, l, c, 0, (i64 *)pz));
+        G_TRY(mpcx_d2h(ctx, Z + row0 * c, pz, 8 * mc));
+#undef G_TRY
+        return release(0);
+    });
+}
+
 } // extern "C"

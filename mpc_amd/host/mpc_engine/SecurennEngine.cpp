@@ -76,6 +76,8 @@ void SecurennEngine::matrix_mul(const MatrixXl &Xj, const MatrixXl &Yj, MatrixXl
     MSG_CHECK(message_recv[2].size() == (na + nb + nc) * W);
     Dev<int64_t> triple(gpu, na + nb + nc), ef(gpu, na + nb), ef_peer(gpu, na + nb);
     upload_string(triple, message_recv[2]);
+    string triple_msg; // round 2 overwrites the slot; a group reads the triple from the host once more
+    if (group) triple_msg.swap(message_recv[2]);
     {
         Dev<int64_t> x(gpu, Xj.data(), na), y(gpu, Yj.data(), nb);
         GPU_OK(gpu, mpcx_snn_beaver_party_open_matmul(gpu, x, y, 1, triple, rows, lens, cols, ef));
@@ -84,10 +86,23 @@ void SecurennEngine::matrix_mul(const MatrixXl &Xj, const MatrixXl &Yj, MatrixXl
     message_send[2].clear();
     messenger->send_and_recv(message_send, message_recv); // round 2
     MSG_CHECK(message_recv[peer].size() == (na + nb) * W);
+    Zj.resize(rows, cols);
+    if (group && rows && lens && cols) {
+        // row blocks over the group's GPUs, straight from the three messages; the product comes back row-major
+        VecI64 zr(nc);
+        if (mpcx_group_snn_beaver_party_finish_matmul(group, (int)party_id, (const int64_t *)triple_msg.data(),
+                                                      (const int64_t *)message_send[peer].data(),
+                                                      (const int64_t *)message_recv[peer].data(), rows, lens, cols,
+                                                      zr.data()) != 0) {
+            fprintf(stderr, "mpcx_group_snn_beaver_party_finish_matmul: %s\n", mpcx_group_last_error(group));
+            abort();
+        }
+        vecI642matrix(zr, Zj);
+        return;
+    }
     upload_string(ef_peer, message_recv[peer]);
     Dev<int64_t> z(gpu, nc);
     GPU_OK(gpu, mpcx_snn_beaver_party_finish_matmul(gpu, (int)party_id, triple, ef, ef_peer, rows, lens, cols, 1, z));
-    Zj.resize(rows, cols);
     z.down(Zj.data(), nc);
 }
 

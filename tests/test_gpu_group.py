@@ -50,6 +50,27 @@ def test_group_matmul_equals_the_oracle(lib, orc, members, r, l, c, layout):
         lib.mpcx_group_shutdown(g)
 
 
+@pytest.mark.parametrize("members", [1, 3])
+@pytest.mark.parametrize("party", [0, 1])
+@pytest.mark.parametrize("r,l,c", [(300, 70, 130), (5, 4, 3), (700, 260, 128)])
+def test_group_beaver_finish_equals_the_oracle(lib, orc, members, party, r, l, c):
+    """mpcx_group_snn_beaver_party_finish_matmul on the host messages of SecurennEngine::matrix_mul: the members' row
+    blocks, each written into its place of Z, are the oracle's Z = C + E B + A F + party E F."""
+    g = ctypes.c_void_p()
+    assert lib.mpcx_group_init((I32 * members)(*([0] * members)), I32(members), ctypes.byref(g)) == 0
+    try:
+        rng = np.random.default_rng(r + 7 * party + members)
+        triple = rng.integers(-2 ** 63, 2 ** 63, r * l + l * c + r * c, dtype=np.int64)
+        ef_own, ef_peer = (rng.integers(-2 ** 63, 2 ** 63, r * l + l * c, dtype=np.int64) for _ in range(2))
+        Z = np.zeros(r * c, dtype=np.int64)
+        rc = lib.mpcx_group_snn_beaver_party_finish_matmul(g, I32(party), ptr(triple), ptr(ef_own), ptr(ef_peer), U64(r),
+                                                           U64(l), U64(c), ptr(Z))
+        assert rc == 0, lib.mpcx_group_last_error(g)
+        assert np.array_equal(Z, orc.snn_beaver_party_finish_matmul(party, triple, ef_own, ef_peer, r, l, c, 0))
+    finally:
+        lib.mpcx_group_shutdown(g)
+
+
 def test_group_for_each_ranges(lib):
     """The planner cuts [0, n) into contiguous multiples of the granule, and every member's callback sees its range."""
     g = ctypes.c_void_p()
@@ -108,7 +129,8 @@ def test_host_benchmark_over_a_group_verifies():
 @pytest.mark.parametrize("engine", ["securenn", "my"])
 def test_host_additive_engines_benchmark_over_a_group_verifies(engine):
     """benchmark1's SecureNN / MyEngine lines (msb + vector_mul / bit_inject on 100 000 elements in ranges over three
-    contexts, matrix_mul on the first): the program checks every result against the plain computation."""
+    contexts; SecureNN's matrix_mul finishes in row blocks over them, MyEngine's runs on the first): the program checks
+    every result against the plain computation."""
     exe = os.path.join(HOST, "benchmark1")
     assert os.path.exists(exe), "mpc_amd/host/benchmark1 missing: run __graft_entry__.build()"
     r = subprocess.run([exe, "--engine", engine, "--width", "256", "--vec", "100000", "--repeat", "1", "--no-mlp"],
