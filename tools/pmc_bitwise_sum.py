@@ -20,6 +20,7 @@ ALGO = {
     "bi_post_kernel": ("with the ReLU minuend, averaged over the three parties: messages and select bytes 25 / 25 / 50 B "
                        "+ 16 B minuend in, 16 B out (57, 57, 82 B)", 196 / 3),
     "beaver_deal_vec_kernel": ("6 x 8 B out, 12 stream words x 0.375 B of checkpoints in", 52.5),
+    "my_bi_deal_kernel": ("8 x 8 B out, 12 stream words x 0.375 B of checkpoints in", 68.5),
 }
 MSB = ["msb_round_pre_kernel", "msb_round_mid_kernel", "msb_round_post_kernel"]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
