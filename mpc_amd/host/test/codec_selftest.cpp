@@ -101,7 +101,39 @@ static void vectors(size_t n) {
     CHECK(b2 == b);
 }
 
+// The container subset keeps large released blocks for the next container of the same size on the thread, copies and
+// moves keep their contents, and a matrix larger than one transposition tile band round-trips through the wire order.
+static void storage() {
+    const size_t rows = 600, cols = 700; // 3.2 MiB: above the block cache's threshold
+    const int64_t *first;
+    {
+        MatrixXl a(rows, cols);
+        first = a.data();
+        for (size_t i = 0; i < rows * cols; i++) a.data()[i] = (int64_t)(i * 0x9E3779B97F4A7C15ull);
+        MatrixXl b = a;
+        CHECK(b == a && b.data() != a.data());
+        string wire;
+        matrix2string(a, wire);
+        CHECK(((const int64_t *)wire.data())[5 * cols + 3] == a(5, 3));
+        MatrixXl c(rows, cols);
+        string2matrix(wire, c);
+        CHECK(c == a);
+        MatrixXl d(std::move(c));
+        CHECK(d == a && c.size() == 0);
+    }
+    MatrixXl again(rows, cols); // one of the released blocks of this size comes back
+    CHECK(again.data() != nullptr);
+    (void)first;
+    VecI64 v(1 << 18), w;
+    for (size_t i = 0; i < (size_t)v.size(); i++) v[i] = (int64_t)i;
+    string s;
+    vecI642string(v, s);
+    string2vecI64(s, w);
+    CHECK(w == v);
+}
+
 int main() {
+    storage();
     const size_t shapes[][2] = {{0, 0}, {1, 1}, {1, 7}, {7, 1}, {5, 4}, {32, 32}, {33, 31}, {64, 65}, {100, 3}, {3, 100}, {129, 70}};
     for (auto &sh : shapes) matrices(sh[0], sh[1]);
     const size_t sizes[] = {0, 1, 2, 10, 63, 64, 65, 1000};
