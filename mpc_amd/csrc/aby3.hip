@@ -755,10 +755,14 @@ struct BiPostArgs {
 // one output of a window: TWO = G_k is the sum of two sections, SEL = the unmasked message is added, SUB = the minuend.
 // Both candidate message words are loaded and one is chosen afterwards, so that no load waits for the select byte;
 // the arrays are compile-time present or absent, which lets the loads of four elements run together.
-template <bool TWO, bool SEL, bool SUB>
+// elements of a window (32 measured the same: the run length is not what bounds the pass)
+#ifndef BI_POST_WIN
+#define BI_POST_WIN 16
+#endif
+template <bool TWO, bool SEL, bool SUB, bool PAIRS>
 __device__ inline void bi_post_pass(const BiPostArgs &P, const u32 k, BiGen &ga, BiGen &gb, u64 *tile, u64 *row_tile,
                                     const u32 tid, const u64 lane0, const u32 win) {
-    constexpr u32 EPL = 64, WIN = 16, PITCH = WIN + 1;
+    constexpr u32 EPL = 64, WIN = BI_POST_WIN, PITCH = WIN + 1;
 #pragma unroll
     for (u32 j = 0; j < WIN; j++) row_tile[j] = TWO ? ga.next() + gb.next() : ga.next();
     prg_wave_sync();
@@ -766,27 +770,57 @@ __device__ inline void bi_post_pass(const BiPostArgs &P, const u32 k, BiGen &ga,
     const u64 *__restrict__ lo = P.lo[k], *__restrict__ hi = P.hi[k], *__restrict__ x = P.x[k];
     const u64 *__restrict__ sub = P.sub[k];
     u64 *__restrict__ out = P.out[k];
+    if (PAIRS) {
+        // every array is 16-byte aligned: a lane finishes two neighbouring elements with 16-byte accesses
 #pragma unroll 4
-    for (u32 j = 0; j < WIN; j++) {
-        const u32 idx = j * 64 + (tid & 63);
-        const u32 row = (tid & ~63u) + idx / WIN, col = idx % WIN;
-        const u64 e = (lane0 + row) * EPL + win * WIN + col;
-        if (e < P.n) {
-            u64 v = tile[row * PITCH + col];
-            if (SEL) {
-                const u64 m0 = lo[e], m1 = hi[e], w = x[e];
-                v += (sel[e] == 1 ? m1 : m0) ^ w;
+        for (u32 j = 0; j < WIN / 2; j++) {
+            const u32 idx = j * 64 + (tid & 63);
+            const u32 row = (tid & ~63u) + idx / (WIN / 2), col = 2 * (idx % (WIN / 2));
+            const u64 e = (lane0 + row) * EPL + win * WIN + col;
+            if (e + 2 <= P.n) {
+                u64 v0 = tile[row * PITCH + col], v1 = tile[row * PITCH + col + 1];
+                if (SEL) {
+                    const ulonglong2 m0 = *(const ulonglong2 *)(lo + e), m1 = *(const ulonglong2 *)(hi + e);
+                    const ulonglong2 w = *(const ulonglong2 *)(x + e);
+                    const u32 sb = *(const u16 *)(sel + e);
+                    v0 += ((sb & 0xFF) == 1 ? m1.x : m0.x) ^ w.x;
+                    v1 += ((sb >> 8) == 1 ? m1.y : m0.y) ^ w.y;
+                }
+                if (SUB) {
+                    const ulonglong2 sv = *(const ulonglong2 *)(sub + e);
+                    v0 = sv.x - v0, v1 = sv.y - v1;
+                }
+                *(ulonglong2 *)(out + e) = make_ulonglong2(v0, v1);
+            } else if (e < P.n) { // the last element of an odd-length call
+                u64 v = tile[row * PITCH + col];
+                if (SEL) v += (sel[e] == 1 ? hi[e] : lo[e]) ^ x[e];
+                if (SUB) v = sub[e] - v;
+                out[e] = v;
             }
-            if (SUB) v = sub[e] - v;
-            out[e] = v;
+        }
+    } else {
+#pragma unroll 4
+        for (u32 j = 0; j < WIN; j++) {
+            const u32 idx = j * 64 + (tid & 63);
+            const u32 row = (tid & ~63u) + idx / WIN, col = idx % WIN;
+            const u64 e = (lane0 + row) * EPL + win * WIN + col;
+            if (e < P.n) {
+                u64 v = tile[row * PITCH + col];
+                if (SEL) {
+                    const u64 m0 = lo[e], m1 = hi[e], w = x[e];
+                    v += (sel[e] == 1 ? m1 : m0) ^ w;
+                }
+                if (SUB) v = sub[e] - v;
+                out[e] = v;
+            }
         }
     }
     prg_wave_sync();
 }
 // PARTY 0: output 0 = one section + message, output 1 = two sections; PARTY 1: the other way round; PARTY 2: both
 // outputs one section + message.
-template <int PARTY, bool SUB> __global__ __launch_bounds__(256) void bi_post_kernel(BiPostArgs P) {
-    constexpr u32 EPL = 64, WIN = 16, PITCH = WIN + 1;
+template <int PARTY, bool SUB, bool PAIRS> __global__ __launch_bounds__(256) void bi_post_kernel(BiPostArgs P) {
+    constexpr u32 EPL = 64, WIN = BI_POST_WIN, PITCH = WIN + 1;
     constexpr bool TWO0 = PARTY == 1, TWO1 = PARTY == 0;
     __shared__ u64 tile[256 * PITCH];
     const u32 tid = threadIdx.x;
@@ -801,20 +835,33 @@ template <int PARTY, bool SUB> __global__ __launch_bounds__(256) void bi_post_ke
     u64 *row_tile = tile + tid * PITCH;
 #pragma unroll 1
     for (u32 win = 0; win < EPL / WIN; win++) {
-        bi_post_pass<TWO0, !TWO0, SUB>(P, 0, g[0][0], g[0][1], tile, row_tile, tid, lane0, win);
-        bi_post_pass<TWO1, !TWO1, SUB>(P, 1, g[1][0], g[1][1], tile, row_tile, tid, lane0, win);
+        bi_post_pass<TWO0, !TWO0, SUB, PAIRS>(P, 0, g[0][0], g[0][1], tile, row_tile, tid, lane0, win);
+        bi_post_pass<TWO1, !TWO1, SUB, PAIRS>(P, 1, g[1][0], g[1][1], tile, row_tile, tid, lane0, win);
     }
 }
 int bi_post_launch(mpcx_ctx *ctx, int party, const BiPostArgs &P) {
     const u64 grid = ceil_div(ceil_div(P.n, 64), 256);
     MPCX_REQUIRE(grid < (1ull << 31), "bit_inject: range too large for one launch");
     const bool sub = P.sub[0] != nullptr;
+    uintptr_t bits = 0; // two elements per lane and access when every array in use starts on a 16-byte boundary
+    for (int k = 0; k < 2; k++)
+        bits |= (uintptr_t)P.lo[k] | (uintptr_t)P.hi[k] | (uintptr_t)P.x[k] | (uintptr_t)P.sub[k] | (uintptr_t)P.out[k] |
+                ((uintptr_t)P.sel[k] & 1) * 8;
+    const bool pairs = (bits & 15) == 0;
     ProfScope ps(ctx, PROF_PRG);
+#define BI_POST_LAUNCH(PARTY, SUBF, PAIRSF)                                                                             \
+    hipLaunchKernelGGL((bi_post_kernel<PARTY, SUBF, PAIRSF>), dim3((u32)grid), dim3(256), 0, ctx->stream, P)
 #define BI_POST(PARTY)                                                                                                 \
-    if (sub)                                                                                                           \
-        hipLaunchKernelGGL((bi_post_kernel<PARTY, true>), dim3((u32)grid), dim3(256), 0, ctx->stream, P);              \
-    else                                                                                                               \
-        hipLaunchKernelGGL((bi_post_kernel<PARTY, false>), dim3((u32)grid), dim3(256), 0, ctx->stream, P)
+    do {                                                                                                               \
+        if (sub && pairs)                                                                                              \
+            BI_POST_LAUNCH(PARTY, true, true);                                                                         \
+        else if (sub)                                                                                                  \
+            BI_POST_LAUNCH(PARTY, true, false);                                                                        \
+        else if (pairs)                                                                                                \
+            BI_POST_LAUNCH(PARTY, false, true);                                                                        \
+        else                                                                                                           \
+            BI_POST_LAUNCH(PARTY, false, false);                                                                       \
+    } while (0)
     if (party == 0) {
         BI_POST(0);
     } else if (party == 1) {
@@ -822,6 +869,7 @@ int bi_post_launch(mpcx_ctx *ctx, int party, const BiPostArgs &P) {
     } else {
         BI_POST(2);
     }
+#undef BI_POST_LAUNCH
 #undef BI_POST
     MPCX_LAUNCH_CHECK();
     return 0;
