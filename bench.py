@@ -683,7 +683,9 @@ def main():
                          "issued": issued, "issued_frac": issued / INT8_PEAK_TOPS, "int8_products_per_multiply_add": nprod,
                          "gemm_phase": phase, "gemm_phase_frac": phase / INT8_PEAK_TOPS,
                          "traffic": measured_traffic(args.size, world, kernel),
-                         "traffic_unit": f"bytes per launch ({PMC_SUMMARY})",
+                         "traffic_unit": f"bytes per launch ({PMC_SUMMARY}: FETCH_SIZE x 2 + WRITE_SIZE, counted between "
+                                         "the L2s and the fabric, i.e. in front of the 256 MB memory-side cache; the planes "
+                                         "of a launch are 1.2 GB and are read by every tile row / column that needs them)",
                          "avg_launch_ms": avg_s * 1e3, "launches": gemm_cnt,
                          "note": "achieved = algorithmic int8 TOP/s: 36 digit pairs x 2 x rows x c x 2l per product over the "
                                  "summed launch time of the GEMM kernel; issued = the int8 operations the kernel executes "
