@@ -243,6 +243,11 @@ int mpcx_snn_add_zp(mpcx_ctx *ctx, const uint16_t *a, const uint16_t *b, uint16_
  * Z = C + E*B + A*F + party*E*F, written in layoutZ */
 int mpcx_snn_beaver_dealer_matmul(mpcx_ctx *ctx, uint64_t seedS, uint64_t r, uint64_t l, uint64_t c, int64_t *msg0,
                                   int64_t *msg1);
+/* the dealer's triple for rows [row0, row0 + rows) of the product: the rows of A_i and C_i (rows x l, rows x c) and, when
+ * B0 / B1 are non-NULL, all of B_i (l x c) -- the row-block form that spreads the dealer's product over GPUs */
+int mpcx_snn_beaver_dealer_matmul_rows(mpcx_ctx *ctx, uint64_t seedS, uint64_t r, uint64_t l, uint64_t c, uint64_t row0,
+                                       uint64_t rows, int64_t *A0, int64_t *A1, int64_t *B0, int64_t *B1, int64_t *C0,
+                                       int64_t *C1);
 int mpcx_snn_beaver_party_open_matmul(mpcx_ctx *ctx, const int64_t *X, const int64_t *Y, int layout,
                                       const int64_t *triple, uint64_t r, uint64_t l, uint64_t c, int64_t *ef_out);
 int mpcx_snn_beaver_party_finish_matmul(mpcx_ctx *ctx, int party, const int64_t *triple, const int64_t *ef_own,
@@ -398,6 +403,11 @@ int mpcx_group_aby3_matmul_local(mpcx_group *g, const int64_t *X0, const int64_t
  * every member uploads its rows of A, C and E and all of B and F, and writes its rows of Z into place. */
 int mpcx_group_snn_beaver_party_finish_matmul(mpcx_group *g, int party, const int64_t *triple, const int64_t *ef_own,
                                               const int64_t *ef_peer, uint64_t r, uint64_t l, uint64_t c, int64_t *Z);
+/* mpcx_snn_beaver_dealer_matmul (SecurennEngine.cpp:72-110) over the group: msg0, msg1 (A_i | B_i | C_i, r l + l c + r c
+ * words each) are HOST pointers; every member deals the rows of A_i and C_i of its row block into place, the first
+ * member also B_i. */
+int mpcx_group_snn_beaver_dealer_matmul(mpcx_group *g, uint64_t seedS, uint64_t r, uint64_t l, uint64_t c, int64_t *msg0,
+                                        int64_t *msg1);
 
 #ifdef __cplusplus
 }

@@ -277,4 +277,39 @@ int mpcx_group_snn_beaver_party_finish_matmul(mpcx_group *g, int party, const in
     });
 }
 
+
+// SecurennEngine::matrix_mul, party 2 before round 1 (SecurennEngine.cpp:72-110): the dealer's product
+// C_1 = (A_0 + A_1)(B_0 + B_1) - C_0 in row blocks; every member writes the rows it dealt into the two host messages.
+int mpcx_group_snn_beaver_dealer_matmul(mpcx_group *g, uint64_t seedS, uint64_t r, uint64_t l, uint64_t c, int64_t *msg0,
+                                        int64_t *msg1) {
+    if (!g) return group_fail(g, "mpcx_group_snn_beaver_dealer_matmul: the group is NULL");
+    if (!(msg0 && msg1)) return group_fail(g, "mpcx_group_snn_beaver_dealer_matmul: NULL pointer");
+    if (!(r && l && c)) return group_fail(g, "mpcx_group_snn_beaver_dealer_matmul: empty shape");
+    int members = (int)g->ctx.size();
+    const u64 granule = 128;
+    if (ceil_div(r, granule) < (u64)members) members = (int)ceil_div(r, granule);
+    const u64 na = r * l, nb = l * c;
+    return group_run(g, members, [=](int k) -> int {
+        mpcx_ctx *ctx = g->ctx[k];
+        u64 row0 = 0, rows = 0;
+        mpcx_plan_split(r, members, k, granule, &row0, &rows);
+        if (rows == 0) return 0;
+        const u64 ma = rows * l, mc = rows * c;
+        const bool with_b = k == 0; // B_i travels once
+        void *buf = nullptr;
+        if (mpcx_malloc(ctx, 8 * (2 * ma + 2 * mc + (with_b ? 2 * nb : 0)), &buf) != 0) return 1;
+        i64 *a0 = (i64 *)buf, *a1 = a0 + ma, *c0 = a1 + ma, *c1 = c0 + mc, *b0 = with_b ? c1 + mc : nullptr,
+            *b1 = with_b ? b0 + nb : nullptr;
+        int rc = mpcx_snn_beaver_dealer_matmul_rows(ctx, seedS, r, l, c, row0, rows, a0, a1, b0, b1, c0, c1);
+        if (!rc) rc = mpcx_d2h(ctx, msg0 + row0 * l, a0, 8 * ma);
+        if (!rc) rc = mpcx_d2h(ctx, msg1 + row0 * l, a1, 8 * ma);
+        if (!rc) rc = mpcx_d2h(ctx, msg0 + na + nb + row0 * c, c0, 8 * mc);
+        if (!rc) rc = mpcx_d2h(ctx, msg1 + na + nb + row0 * c, c1, 8 * mc);
+        if (!rc && with_b) rc = mpcx_d2h(ctx, msg0 + na, b0, 8 * nb);
+        if (!rc && with_b) rc = mpcx_d2h(ctx, msg1 + na, b1, 8 * nb);
+        (void)mpcx_free(ctx, buf);
+        return rc;
+    });
+}
+
 } // extern "C"

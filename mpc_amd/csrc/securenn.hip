@@ -454,26 +454,42 @@ int mpcx_snn_add_zp(mpcx_ctx *ctx, const uint16_t *a, const uint16_t *b, uint16_
 }
 
 // ---- Beaver matmul
+// rows [row0, row0 + rows) of the dealer's triple of an r x l . l x c product: the rows of A_i, C_i and -- when B0 / B1
+// are given -- the whole of B_i (SecurennEngine.cpp:80, :92, :103: consecutive slices of the self stream's buffer),
+// C_1 = (A_0 + A_1)(B_0 + B_1) - C_0 (:106-107) for these rows.  B0 / B1 may be NULL for a caller that needs only the
+// row parts (the B slices are then made in scratch).
+int mpcx_snn_beaver_dealer_matmul_rows(mpcx_ctx *ctx, uint64_t seedS, uint64_t r, uint64_t l, uint64_t c, uint64_t row0,
+                                       uint64_t rows, int64_t *A0, int64_t *A1, int64_t *B0, int64_t *B1, int64_t *C0,
+                                       int64_t *C1) {
+    MPCX_REQUIRE(A0 && A1 && C0 && C1, "mpcx_snn_beaver_dealer_matmul_rows: NULL pointer");
+    MPCX_REQUIRE(!B0 == !B1, "mpcx_snn_beaver_dealer_matmul_rows: B0 and B1 go together");
+    MPCX_REQUIRE(r && l && c && rows, "mpcx_snn_beaver_dealer_matmul_rows: empty shape");
+    MPCX_REQUIRE(row0 <= r && rows <= r - row0, "mpcx_snn_beaver_dealer_matmul_rows: rows [%llu, +%llu) outside %llu rows",
+                 (unsigned long long)row0, (unsigned long long)rows, (unsigned long long)r);
+    const u64 na = r * l, nb = l * c, ma = rows * l, mc = rows * c;
+    const u64 gemm_bytes = ring_gemm_ws_bytes(1, rows, l, c);
+    void *ws;
+    MPCX_TRY(mpcx_ws(ctx, gemm_bytes + 8 * (ma + (B0 ? 0 : 2 * nb)), &ws));
+    u64 *As = (u64 *)((u8 *)ws + gemm_bytes);
+    i64 *b0 = B0 ? B0 : (i64 *)(As + ma), *b1 = B1 ? B1 : b0 + nb;
+    MPCX_TRY(prg_fill_words(ctx, seedS, 0, 2 * (row0 * l), ma, 2, A0, nullptr));
+    MPCX_TRY(prg_fill_words(ctx, seedS, 0, 2 * (na + row0 * l), ma, 2, A1, nullptr));
+    MPCX_TRY(prg_fill_words(ctx, seedS, 0, 2 * (2 * na), nb, 2, b0, nullptr));
+    MPCX_TRY(prg_fill_words(ctx, seedS, 0, 2 * (2 * na + nb), nb, 2, b1, nullptr));
+    MPCX_TRY(prg_fill_words(ctx, seedS, 0, 2 * (2 * na + 2 * nb + row0 * c), mc, 2, C0, nullptr));
+    const u64 *a0 = (const u64 *)A0, *a1 = (const u64 *)A1;
+    MPCX_TRY(ew_launch(ctx, ma, [=] __device__(u64 i) { As[i] = a0[i] + a1[i]; }));
+    GemmPart p{(const i64 *)As, b0, b1};
+    return ring_gemm_parts(ctx, &p, 1, rows, l, c, 0, 0, nullptr, C0, C1, 0, 0);
+}
+
 int mpcx_snn_beaver_dealer_matmul(mpcx_ctx *ctx, uint64_t seedS, uint64_t r, uint64_t l, uint64_t c, int64_t *msg0,
                                   int64_t *msg1) {
     MPCX_REQUIRE(msg0 && msg1, "mpcx_snn_beaver_dealer_matmul: NULL pointer");
     MPCX_REQUIRE(r && l && c, "mpcx_snn_beaver_dealer_matmul: empty shape");
-    const u64 na = r * l, nb = l * c, nc = r * c;
-    // SecurennEngine.cpp:80,92,103: A_i, B_i, C_0 are consecutive slices of the self stream's buffer
-    MPCX_TRY(prg_fill_words(ctx, seedS, 0, 0, na, 2, msg0, nullptr));
-    MPCX_TRY(prg_fill_words(ctx, seedS, 0, 2 * na, na, 2, msg1, nullptr));
-    MPCX_TRY(prg_fill_words(ctx, seedS, 0, 2 * (2 * na), nb, 2, msg0 + na, nullptr));
-    MPCX_TRY(prg_fill_words(ctx, seedS, 0, 2 * (2 * na + nb), nb, 2, msg1 + na, nullptr));
-    MPCX_TRY(prg_fill_words(ctx, seedS, 0, 2 * (2 * na + 2 * nb), nc, 2, msg0 + na + nb, nullptr));
-    // C_1 = (A_0 + A_1)(B_0 + B_1) - C_0  (:106-107)
-    const u64 gemm_bytes = ring_gemm_ws_bytes(1, r, l, c);
-    void *ws;
-    MPCX_TRY(mpcx_ws(ctx, gemm_bytes + 8 * na, &ws));
-    u64 *As = (u64 *)((u8 *)ws + gemm_bytes);
-    const u64 *a0 = (const u64 *)msg0, *a1 = (const u64 *)msg1;
-    MPCX_TRY(ew_launch(ctx, na, [=] __device__(u64 i) { As[i] = a0[i] + a1[i]; }));
-    GemmPart p{(const i64 *)As, msg0 + na, msg1 + na};
-    return ring_gemm_parts(ctx, &p, 1, r, l, c, 0, 0, nullptr, msg0 + na + nb, msg1 + na + nb, 0, 0);
+    const u64 na = r * l, nb = l * c;
+    return mpcx_snn_beaver_dealer_matmul_rows(ctx, seedS, r, l, c, 0, r, msg0, msg1, msg0 + na, msg1 + na, msg0 + na + nb,
+                                              msg1 + na + nb);
 }
 
 int mpcx_snn_beaver_party_open_matmul(mpcx_ctx *ctx, const int64_t *X, const int64_t *Y, int layout,

@@ -59,10 +59,20 @@ void SecurennEngine::matrix_mul(const MatrixXl &Xj, const MatrixXl &Yj, MatrixXl
     assert(Yj.rows() == lens);
     const size_t na = rows * lens, nb = lens * cols, nc = rows * cols;
     if (party_id == 2) {
-        Dev<int64_t> m0(gpu, na + nb + nc), m1(gpu, na + nb + nc);
-        GPU_OK(gpu, mpcx_snn_beaver_dealer_matmul(gpu, prgs[2].init_seed, rows, lens, cols, m0, m1));
-        m0.to_string(message_send[0]);
-        m1.to_string(message_send[1]);
+        if (group && rows && lens && cols) { // the dealer's product in row blocks, dealt straight into the two messages
+            message_send[0].resize((na + nb + nc) * W);
+            message_send[1].resize((na + nb + nc) * W);
+            if (mpcx_group_snn_beaver_dealer_matmul(group, prgs[2].init_seed, rows, lens, cols, (int64_t *)&message_send[0][0],
+                                                    (int64_t *)&message_send[1][0]) != 0) {
+                fprintf(stderr, "mpcx_group_snn_beaver_dealer_matmul: %s\n", mpcx_group_last_error(group));
+                abort();
+            }
+        } else {
+            Dev<int64_t> m0(gpu, na + nb + nc), m1(gpu, na + nb + nc);
+            GPU_OK(gpu, mpcx_snn_beaver_dealer_matmul(gpu, prgs[2].init_seed, rows, lens, cols, m0, m1));
+            m0.to_string(message_send[0]);
+            m1.to_string(message_send[1]);
+        }
         messenger->send_and_recv(message_send, message_recv); // round 1
         message_send[0].clear();
         message_send[1].clear();

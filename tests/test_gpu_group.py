@@ -71,6 +71,25 @@ def test_group_beaver_finish_equals_the_oracle(lib, orc, members, party, r, l, c
         lib.mpcx_group_shutdown(g)
 
 
+@pytest.mark.parametrize("members", [1, 2, 3])
+@pytest.mark.parametrize("r,l,c", [(300, 70, 130), (5, 4, 3), (700, 260, 128)])
+def test_group_beaver_dealer_equals_the_oracle(lib, orc, members, r, l, c):
+    """mpcx_group_snn_beaver_dealer_matmul: the members deal the rows of A_i and C_i of their row blocks (the first one
+    B_i as well) straight into the two host messages, which are the oracle's A_i | B_i | C_i."""
+    from oracle_lib import KEYS
+    g = ctypes.c_void_p()
+    assert lib.mpcx_group_init((I32 * members)(*([0] * members)), I32(members), ctypes.byref(g)) == 0
+    try:
+        size = r * l + l * c + r * c
+        m0, m1 = np.full(size, -1, dtype=np.int64), np.full(size, -1, dtype=np.int64)
+        rc = lib.mpcx_group_snn_beaver_dealer_matmul(g, U64(KEYS), U64(r), U64(l), U64(c), ptr(m0), ptr(m1))
+        assert rc == 0, lib.mpcx_group_last_error(g)
+        w0, w1 = orc.snn_beaver_dealer_matmul(KEYS, r, l, c)
+        assert np.array_equal(m0, w0) and np.array_equal(m1, w1)
+    finally:
+        lib.mpcx_group_shutdown(g)
+
+
 def test_group_for_each_ranges(lib):
     """The planner cuts [0, n) into contiguous multiples of the granule, and every member's callback sees its range."""
     g = ctypes.c_void_p()
