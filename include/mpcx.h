@@ -336,6 +336,14 @@ int mpcx_my_beaver_party_open_matmul(mpcx_ctx *ctx, const int64_t *X, const int6
 int mpcx_my_beaver_party_finish_matmul(mpcx_ctx *ctx, int party, uint64_t seed2, const int64_t *C, const int64_t *ef_own,
                                        const int64_t *ef_peer, uint64_t r, uint64_t l, uint64_t c, int layoutZ,
                                        int64_t *Z);
+/* the row-block forms: rows [row0, row0 + rows) of the r x l . l x c product.  dealer: C0 / C1 hold rows x c words.
+ * finish: C holds rows x c words, ef_own / ef_peer the rows of E (rows x l) followed by all of F (l x c); A and B are read
+ * from the stream at their places in the whole product; Z (rows x c) in layoutZ. */
+int mpcx_my_beaver_dealer_matmul_rows(mpcx_ctx *ctx, uint64_t seed0, uint64_t seed1, uint64_t seedS, uint64_t r, uint64_t l,
+                                      uint64_t c, uint64_t row0, uint64_t rows, int64_t *C0, int64_t *C1);
+int mpcx_my_beaver_party_finish_matmul_rows(mpcx_ctx *ctx, int party, uint64_t seed2, const int64_t *C, const int64_t *ef_own,
+                                            const int64_t *ef_peer, uint64_t r, uint64_t l, uint64_t c, uint64_t row0,
+                                            uint64_t rows, int layoutZ, int64_t *Z);
 /* vector_mul (:221-280), one round; ef = E[n] | F[n] */
 int mpcx_my_beaver_dealer_vecmul(mpcx_ctx *ctx, uint64_t seed0, uint64_t seed1, uint64_t seedS, uint64_t n_total,
                                  uint64_t i0, uint64_t n, int64_t *C0, int64_t *C1);
@@ -408,6 +416,14 @@ int mpcx_group_snn_beaver_party_finish_matmul(mpcx_group *g, int party, const in
  * member also B_i. */
 int mpcx_group_snn_beaver_dealer_matmul(mpcx_group *g, uint64_t seedS, uint64_t r, uint64_t l, uint64_t c, int64_t *msg0,
                                         int64_t *msg1);
+/* MyEngine::matrix_mul (MyEngine.cpp:145-219) over the group, host pointers throughout: the dealer's C_0 / C_1 (r x c,
+ * row-major = the messages), and the parties' Z (r x c, row-major) from C, ef_own and ef_peer (E | F) as the messages
+ * carry them. */
+int mpcx_group_my_beaver_dealer_matmul(mpcx_group *g, uint64_t seed0, uint64_t seed1, uint64_t seedS, uint64_t r,
+                                       uint64_t l, uint64_t c, int64_t *C0, int64_t *C1);
+int mpcx_group_my_beaver_party_finish_matmul(mpcx_group *g, int party, uint64_t seed2, const int64_t *C,
+                                             const int64_t *ef_own, const int64_t *ef_peer, uint64_t r, uint64_t l,
+                                             uint64_t c, int64_t *Z);
 
 #ifdef __cplusplus
 }

@@ -312,4 +312,64 @@ int mpcx_group_snn_beaver_dealer_matmul(mpcx_group *g, uint64_t seedS, uint64_t 
     });
 }
 
+
+// MyEngine::matrix_mul (MyEngine.cpp:145-219) in row blocks: the dealer's C_0 / C_1 rows land in the two host messages,
+// the parties' Z rows in the caller's row-major buffer.
+int mpcx_group_my_beaver_dealer_matmul(mpcx_group *g, uint64_t seed0, uint64_t seed1, uint64_t seedS, uint64_t r,
+                                       uint64_t l, uint64_t c, int64_t *C0, int64_t *C1) {
+    if (!g) return group_fail(g, "mpcx_group_my_beaver_dealer_matmul: the group is NULL");
+    if (!(C0 && C1)) return group_fail(g, "mpcx_group_my_beaver_dealer_matmul: NULL pointer");
+    if (!(r && l && c)) return group_fail(g, "mpcx_group_my_beaver_dealer_matmul: empty shape");
+    int members = (int)g->ctx.size();
+    const u64 granule = 128;
+    if (ceil_div(r, granule) < (u64)members) members = (int)ceil_div(r, granule);
+    return group_run(g, members, [=](int k) -> int {
+        mpcx_ctx *ctx = g->ctx[k];
+        u64 row0 = 0, rows = 0;
+        mpcx_plan_split(r, members, k, granule, &row0, &rows);
+        if (rows == 0) return 0;
+        const u64 mc = rows * c;
+        void *buf = nullptr;
+        if (mpcx_malloc(ctx, 16 * mc, &buf) != 0) return 1;
+        i64 *c0 = (i64 *)buf, *c1 = c0 + mc;
+        int rc = mpcx_my_beaver_dealer_matmul_rows(ctx, seed0, seed1, seedS, r, l, c, row0, rows, c0, c1);
+        if (!rc) rc = mpcx_d2h(ctx, C0 + row0 * c, c0, 8 * mc);
+        if (!rc) rc = mpcx_d2h(ctx, C1 + row0 * c, c1, 8 * mc);
+        (void)mpcx_free(ctx, buf);
+        return rc;
+    });
+}
+
+int mpcx_group_my_beaver_party_finish_matmul(mpcx_group *g, int party, uint64_t seed2, const int64_t *C,
+                                             const int64_t *ef_own, const int64_t *ef_peer, uint64_t r, uint64_t l,
+                                             uint64_t c, int64_t *Z) {
+    if (!g) return group_fail(g, "mpcx_group_my_beaver_party_finish_matmul: the group is NULL");
+    if (!(C && ef_own && ef_peer && Z)) return group_fail(g, "mpcx_group_my_beaver_party_finish_matmul: NULL operand");
+    if (!(r && l && c)) return group_fail(g, "mpcx_group_my_beaver_party_finish_matmul: empty shape");
+    if (party != 0 && party != 1) return group_fail(g, "mpcx_group_my_beaver_party_finish_matmul: party %d", party);
+    int members = (int)g->ctx.size();
+    const u64 granule = 128;
+    if (ceil_div(r, granule) < (u64)members) members = (int)ceil_div(r, granule);
+    const u64 na = r * l, nb = l * c;
+    return group_run(g, members, [=](int k) -> int {
+        mpcx_ctx *ctx = g->ctx[k];
+        u64 row0 = 0, rows = 0;
+        mpcx_plan_split(r, members, k, granule, &row0, &rows);
+        if (rows == 0) return 0;
+        const u64 ma = rows * l, mc = rows * c;
+        void *buf = nullptr;
+        if (mpcx_malloc(ctx, 8 * (2 * mc + 2 * (ma + nb)), &buf) != 0) return 1;
+        i64 *cb = (i64 *)buf, *z = cb + mc, *o = z + mc, *q = o + ma + nb;
+        int rc = mpcx_h2d(ctx, cb, C + row0 * c, 8 * mc);
+        if (!rc) rc = mpcx_h2d(ctx, o, ef_own + row0 * l, 8 * ma);
+        if (!rc) rc = mpcx_h2d(ctx, o + ma, ef_own + na, 8 * nb);
+        if (!rc) rc = mpcx_h2d(ctx, q, ef_peer + row0 * l, 8 * ma);
+        if (!rc) rc = mpcx_h2d(ctx, q + ma, ef_peer + na, 8 * nb);
+        if (!rc) rc = mpcx_my_beaver_party_finish_matmul_rows(ctx, party, seed2, cb, o, q, r, l, c, row0, rows, 0, z);
+        if (!rc) rc = mpcx_d2h(ctx, Z + row0 * c, z, 8 * mc);
+        (void)mpcx_free(ctx, buf);
+        return rc;
+    });
+}
+
 } // extern "C"

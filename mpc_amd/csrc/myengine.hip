@@ -136,24 +136,32 @@ __global__ __launch_bounds__(256) void my_bi_deal_kernel(MyDealArgs P) {
 extern "C" {
 
 // ---- Beaver matrix product (MyEngine.cpp:145-219), one round
-int mpcx_my_beaver_dealer_matmul(mpcx_ctx *ctx, uint64_t seed0, uint64_t seed1, uint64_t seedS, uint64_t r, uint64_t l,
-                                 uint64_t c, int64_t *C0, int64_t *C1) {
-    MPCX_REQUIRE(C0 && C1, "mpcx_my_beaver_dealer_matmul: NULL pointer");
-    MPCX_REQUIRE(r && l && c, "mpcx_my_beaver_dealer_matmul: empty shape");
-    const u64 na = r * l, nb = l * c, nc = r * c;
+// rows [row0, row0 + rows) of the dealer's C_0 / C_1 (the row-block form that spreads the product over GPUs)
+int mpcx_my_beaver_dealer_matmul_rows(mpcx_ctx *ctx, uint64_t seed0, uint64_t seed1, uint64_t seedS, uint64_t r, uint64_t l,
+                                      uint64_t c, uint64_t row0, uint64_t rows, int64_t *C0, int64_t *C1) {
+    MPCX_REQUIRE(C0 && C1, "mpcx_my_beaver_dealer_matmul_rows: NULL pointer");
+    MPCX_REQUIRE(r && l && c && rows, "mpcx_my_beaver_dealer_matmul_rows: empty shape");
+    MPCX_REQUIRE(row0 <= r && rows <= r - row0, "mpcx_my_beaver_dealer_matmul_rows: rows [%llu, +%llu) outside %llu rows",
+                 (unsigned long long)row0, (unsigned long long)rows, (unsigned long long)r);
+    const u64 na = r * l, nb = l * c, ma = rows * l, mc = rows * c;
     Tmp t(ctx);
-    MPCX_TRY(t.get(8 * (2 * na + 2 * nb)));
-    u64 *As = (u64 *)t.p, *A1 = As + na, *B0 = A1 + na, *B1 = B0 + nb;
-    // :157-171: A_j then B_j are consecutive slices of stream j's buffer, so one fill per stream covers both
-    MPCX_TRY(buff(ctx, seed0, 0, na, As));
-    MPCX_TRY(buff(ctx, seed1, 0, na, A1));
+    MPCX_TRY(t.get(8 * (2 * ma + 2 * nb)));
+    u64 *As = (u64 *)t.p, *A1 = As + ma, *B0 = A1 + ma, *B1 = B0 + nb;
+    // :157-171: A_j then B_j are consecutive slices of stream j's buffer
+    MPCX_TRY(buff(ctx, seed0, row0 * l, ma, As));
+    MPCX_TRY(buff(ctx, seed1, row0 * l, ma, A1));
     MPCX_TRY(buff(ctx, seed0, na, nb, B0));
     MPCX_TRY(buff(ctx, seed1, na, nb, B1));
-    MPCX_TRY(buff(ctx, seedS, 0, nc, (u64 *)C0)); // :173-176
-    MPCX_TRY(ew_launch(ctx, na, [=] __device__(u64 i) { As[i] += A1[i]; }));
+    MPCX_TRY(buff(ctx, seedS, row0 * c, mc, (u64 *)C0)); // :173-176
+    MPCX_TRY(ew_launch(ctx, ma, [=] __device__(u64 i) { As[i] += A1[i]; }));
     // C_1 = (A_0 + A_1)(B_0 + B_1) - C_0  (:178)
     GemmPart p{(const i64 *)As, (const i64 *)B0, (const i64 *)B1};
-    return ring_gemm_parts(ctx, &p, 1, r, l, c, 0, 0, nullptr, C0, C1, 0, 0);
+    return ring_gemm_parts(ctx, &p, 1, rows, l, c, 0, 0, nullptr, C0, C1, 0, 0);
+}
+int mpcx_my_beaver_dealer_matmul(mpcx_ctx *ctx, uint64_t seed0, uint64_t seed1, uint64_t seedS, uint64_t r, uint64_t l,
+                                 uint64_t c, int64_t *C0, int64_t *C1) {
+    MPCX_REQUIRE(r && l && c, "mpcx_my_beaver_dealer_matmul: empty shape");
+    return mpcx_my_beaver_dealer_matmul_rows(ctx, seed0, seed1, seedS, r, l, c, 0, r, C0, C1);
 }
 
 int mpcx_my_beaver_party_open_matmul(mpcx_ctx *ctx, const int64_t *X, const int64_t *Y, int layout, uint64_t seed2,
@@ -168,20 +176,31 @@ int mpcx_my_beaver_party_open_matmul(mpcx_ctx *ctx, const int64_t *X, const int6
     return mpcx_snn_beaver_party_open_matmul(ctx, X, Y, layout, (const i64 *)t.p, r, l, c, ef_out);
 }
 
+// rows [row0, row0 + rows) of Z (row-major): C, and the E parts of ef_own / ef_peer, hold these rows only (rows x c,
+// rows x l followed by the whole l x c F); A and B are read from the stream at their places in the whole product
+int mpcx_my_beaver_party_finish_matmul_rows(mpcx_ctx *ctx, int party, uint64_t seed2, const int64_t *C, const int64_t *ef_own,
+                                            const int64_t *ef_peer, uint64_t r, uint64_t l, uint64_t c, uint64_t row0,
+                                            uint64_t rows, int layoutZ, int64_t *Z) {
+    MPCX_REQUIRE(party == 0 || party == 1, "mpcx_my_beaver_party_finish_matmul_rows: party %d", party);
+    MPCX_REQUIRE(C && ef_own && ef_peer && Z, "mpcx_my_beaver_party_finish_matmul_rows: NULL pointer");
+    MPCX_REQUIRE(r && l && c && rows, "mpcx_my_beaver_party_finish_matmul_rows: empty shape");
+    MPCX_REQUIRE(row0 <= r && rows <= r - row0, "mpcx_my_beaver_party_finish_matmul_rows: rows [%llu, +%llu) outside %llu rows",
+                 (unsigned long long)row0, (unsigned long long)rows, (unsigned long long)r);
+    const u64 na = r * l, nb = l * c, ma = rows * l, mc = rows * c;
+    Tmp t(ctx);
+    MPCX_TRY(t.get(8 * (ma + nb + mc)));
+    u64 *triple = (u64 *)t.p; // A rows | B | C rows
+    MPCX_TRY(buff(ctx, seed2, row0 * l, ma, triple));
+    MPCX_TRY(buff(ctx, seed2, na, nb, triple + ma));
+    MPCX_TRY(mpcx_d2d(ctx, triple + ma + nb, C, 8 * mc));
+    // Z = C + E*B + A*F + E*F*party (:217)
+    return mpcx_snn_beaver_party_finish_matmul(ctx, party, (const i64 *)triple, ef_own, ef_peer, rows, l, c, layoutZ, Z);
+}
 int mpcx_my_beaver_party_finish_matmul(mpcx_ctx *ctx, int party, uint64_t seed2, const int64_t *C, const int64_t *ef_own,
                                        const int64_t *ef_peer, uint64_t r, uint64_t l, uint64_t c, int layoutZ,
                                        int64_t *Z) {
-    MPCX_REQUIRE(party == 0 || party == 1, "mpcx_my_beaver_party_finish_matmul: party %d", party);
-    MPCX_REQUIRE(C && ef_own && ef_peer && Z, "mpcx_my_beaver_party_finish_matmul: NULL pointer");
     MPCX_REQUIRE(r && l && c, "mpcx_my_beaver_party_finish_matmul: empty shape");
-    const u64 na = r * l, nb = l * c, nc = r * c;
-    Tmp t(ctx);
-    MPCX_TRY(t.get(8 * (na + nb + nc)));
-    u64 *triple = (u64 *)t.p; // A | B | C
-    MPCX_TRY(buff(ctx, seed2, 0, na + nb, triple));
-    MPCX_TRY(mpcx_d2d(ctx, triple + na + nb, C, 8 * nc));
-    // Z = C + E*B + A*F + E*F*party (:217)
-    return mpcx_snn_beaver_party_finish_matmul(ctx, party, (const i64 *)triple, ef_own, ef_peer, r, l, c, layoutZ, Z);
+    return mpcx_my_beaver_party_finish_matmul_rows(ctx, party, seed2, C, ef_own, ef_peer, r, l, c, 0, r, layoutZ, Z);
 }
 
 // ---- Beaver vector product (:221-280), one round

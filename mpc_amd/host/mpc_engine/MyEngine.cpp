@@ -207,12 +207,23 @@ void MyEngine::matrix_mul(const MatrixXl &Xj, const MatrixXl &Yj, MatrixXl &Zj) 
     assert(Yj.rows() == lens);
     const size_t na = rows * lens, nb = lens * cols, nc = rows * cols;
     Zj.resize(rows, cols);
+    const bool spread = group && rows && lens && cols; // row blocks over the group's GPUs
     if (party_id == 2) {
-        Dev<int64_t> c0(gpu, nc), c1(gpu, nc);
-        GPU_OK(gpu, mpcx_my_beaver_dealer_matmul(gpu, prgs[0].init_seed, prgs[1].init_seed, prgs[2].init_seed, rows, lens,
-                                                 cols, c0, c1));
-        c0.to_string(message_send[0]);
-        c1.to_string(message_send[1]);
+        if (spread) {
+            message_send[0].resize(nc * W);
+            message_send[1].resize(nc * W);
+            if (mpcx_group_my_beaver_dealer_matmul(group, prgs[0].init_seed, prgs[1].init_seed, prgs[2].init_seed, rows, lens,
+                                                   cols, (int64_t *)&message_send[0][0], (int64_t *)&message_send[1][0]) != 0) {
+                fprintf(stderr, "mpcx_group_my_beaver_dealer_matmul: %s\n", mpcx_group_last_error(group));
+                abort();
+            }
+        } else {
+            Dev<int64_t> c0(gpu, nc), c1(gpu, nc);
+            GPU_OK(gpu, mpcx_my_beaver_dealer_matmul(gpu, prgs[0].init_seed, prgs[1].init_seed, prgs[2].init_seed, rows,
+                                                     lens, cols, c0, c1));
+            c0.to_string(message_send[0]);
+            c1.to_string(message_send[1]);
+        }
         messenger->send_and_recv(message_send, message_recv);
         return;
     }
@@ -227,6 +238,18 @@ void MyEngine::matrix_mul(const MatrixXl &Xj, const MatrixXl &Yj, MatrixXl &Zj) 
     message_send[2].clear();
     messenger->send_and_recv(message_send, message_recv);
     MSG_CHECK(message_recv[2].size() == nc * W && message_recv[peer].size() == (na + nb) * W);
+    if (spread) { // straight from the three messages; the product comes back row-major
+        VecI64 zr(nc);
+        if (mpcx_group_my_beaver_party_finish_matmul(group, (int)party_id, s2, (const int64_t *)message_recv[2].data(),
+                                                     (const int64_t *)message_send[peer].data(),
+                                                     (const int64_t *)message_recv[peer].data(), rows, lens, cols,
+                                                     zr.data()) != 0) {
+            fprintf(stderr, "mpcx_group_my_beaver_party_finish_matmul: %s\n", mpcx_group_last_error(group));
+            abort();
+        }
+        vecI642matrix(zr, Zj);
+        return;
+    }
     upload_string(c, message_recv[2]);
     upload_string(ef_peer, message_recv[peer]);
     GPU_OK(gpu, mpcx_my_beaver_party_finish_matmul(gpu, (int)party_id, s2, c, ef, ef_peer, rows, lens, cols, 1, z));

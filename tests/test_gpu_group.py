@@ -90,6 +90,34 @@ def test_group_beaver_dealer_equals_the_oracle(lib, orc, members, r, l, c):
         lib.mpcx_group_shutdown(g)
 
 
+@pytest.mark.parametrize("members", [1, 3])
+@pytest.mark.parametrize("r,l,c", [(300, 70, 130), (5, 4, 3), (700, 260, 128)])
+def test_group_my_engine_matmul_equals_the_oracle(lib, members, r, l, c):
+    """MyEngine's matrix_mul over a group: the dealer's C_0 / C_1 and, for both parties, Z = C + E B + A F + party E F in
+    row blocks written into place equal the oracle's whole-matrix segments."""
+    from my_backends import OracleMy
+    from oracle_lib import KEY12, KEYS
+    omy = OracleMy()
+    g = ctypes.c_void_p()
+    assert lib.mpcx_group_init((I32 * members)(*([0] * members)), I32(members), ctypes.byref(g)) == 0
+    try:
+        C0, C1 = np.full(r * c, -1, dtype=np.int64), np.full(r * c, -1, dtype=np.int64)
+        rc = lib.mpcx_group_my_beaver_dealer_matmul(g, U64(KEY20), U64(KEY12), U64(KEYS), U64(r), U64(l), U64(c), ptr(C0), ptr(C1))
+        assert rc == 0, lib.mpcx_group_last_error(g)
+        w0, w1 = omy.my_beaver_dealer_matmul(KEY20, KEY12, KEYS, r, l, c)
+        assert np.array_equal(C0, w0) and np.array_equal(C1, w1)
+        rng = np.random.default_rng(r + members)
+        for party, seed2, C in ((0, KEY20, C0), (1, KEY12, C1)):
+            ef_own, ef_peer = (rng.integers(-2 ** 63, 2 ** 63, r * l + l * c, dtype=np.int64) for _ in range(2))
+            Z = np.zeros(r * c, dtype=np.int64)
+            rc = lib.mpcx_group_my_beaver_party_finish_matmul(g, I32(party), U64(seed2), ptr(C), ptr(ef_own), ptr(ef_peer),
+                                                              U64(r), U64(l), U64(c), ptr(Z))
+            assert rc == 0, lib.mpcx_group_last_error(g)
+            assert np.array_equal(Z, omy.my_beaver_party_finish_matmul(party, seed2, C, ef_own, ef_peer, r, l, c, 0))
+    finally:
+        lib.mpcx_group_shutdown(g)
+
+
 def test_group_for_each_ranges(lib):
     """The planner cuts [0, n) into contiguous multiples of the granule, and every member's callback sees its range."""
     g = ctypes.c_void_p()
@@ -148,8 +176,7 @@ def test_host_benchmark_over_a_group_verifies():
 @pytest.mark.parametrize("engine", ["securenn", "my"])
 def test_host_additive_engines_benchmark_over_a_group_verifies(engine):
     """benchmark1's SecureNN / MyEngine lines (msb + vector_mul / bit_inject on 100 000 elements in ranges over three
-    contexts; SecureNN's matrix_mul finishes in row blocks over them, MyEngine's runs on the first): the program checks
-    every result against the plain computation."""
+    contexts, matrix_mul in row blocks over them): the program checks every result against the plain computation."""
     exe = os.path.join(HOST, "benchmark1")
     assert os.path.exists(exe), "mpc_amd/host/benchmark1 missing: run __graft_entry__.build()"
     r = subprocess.run([exe, "--engine", engine, "--width", "256", "--vec", "100000", "--repeat", "1", "--no-mlp"],
