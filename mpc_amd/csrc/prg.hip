@@ -5,6 +5,7 @@
 // 24-byte state every PRG_CK outputs; one GPU lane then replays one PRG_CK-word segment.  A
 // 256-thread workgroup therefore owns 256 consecutive segments; every 16 steps the lanes
 // park their words in LDS and the workgroup writes them out as whole 128-byte lines.
+#include <sys/stat.h>
 #include <unistd.h>
 
 #include <condition_variable>
@@ -30,8 +31,10 @@ struct Table {
     // last context of the device shuts down.  Growth is geometric, so together they hold less than the live copy.
     std::vector<PrgCk *> retired;
     u64 bg_target = 0;    // checkpoints the background walker has been asked for
+    bool job_queued = false; // a job for this table is in the walker's queue or running
     u64 last_need = 0;    // the previous request, for the rate at which the stream is consumed
     u64 loaded_from_disk = 0, saved_to_disk = 0;
+    u64 disk_seen_size = 0, disk_seen_mtime = 0; // the cache file as ckpt_load last saw it
 };
 struct Key {
     int device;
@@ -64,32 +67,83 @@ Table &table_of(int device, u64 seed, u64 lcg) {
 }
 
 // ---- checkpoints kept on disk.  The keys of the engines are compile-time constants (mpc_engine/ABY3Engine.hpp:10-15),
-// so the serial walk of a stream is the same work in every process and on every rank: with MPCX_CKPT_CACHE=<dir>
-// a table is read from <dir>/prg_<seed>_<lcg>.ckpt before anything is walked, and written back (to a temporary
-// name, then renamed) when it has grown by more than a quarter.  File = 32-byte header {magic, seed, lcg, count}
-// followed by count checkpoints.
-const u64 CKPT_MAGIC = 0x3143504B435850ull + ((u64)PRG_CK << 56);
+// so the serial walk of a stream is the same work in every process and on every rank: a table is read from
+// <dir>/prg_<seed>_<lcg>.ckpt before anything is walked, and written back (to a temporary name, then renamed) when it
+// has grown by more than a quarter.  <dir> = $MPCX_CKPT_CACHE when set (empty: no cache), else $XDG_CACHE_HOME/mpcx,
+// else $HOME/.cache/mpcx.  File = 40-byte header {magic, seed, lcg, count, checksum of the body} followed by count
+// checkpoints.  A file is trusted only when its length is the one its header implies, the checksum matches, its first
+// entry is the state this process computed itself and its last entry follows from the one before by PRG_CK steps;
+// anything else is ignored (and later overwritten).
+const u64 CKPT_MAGIC = 0x3243504B435850ull + ((u64)PRG_CK << 56);
+const u64 CKPT_HDR_BYTES = 40;
 std::string ckpt_path(u64 seed, u64 lcg) {
-    const char *dir = getenv("MPCX_CKPT_CACHE");
-    if (!dir || !*dir) return std::string();
+    std::string dir;
+    const char *env = getenv("MPCX_CKPT_CACHE");
+    if (env) {
+        if (!*env) return std::string();
+        dir = env;
+    } else {
+        const char *xdg = getenv("XDG_CACHE_HOME"), *home = getenv("HOME");
+        if (xdg && *xdg)
+            dir = std::string(xdg);
+        else if (home && *home)
+            dir = std::string(home) + "/.cache";
+        else
+            return std::string();
+        (void)mkdir(dir.c_str(), 0700); // the parent, then the library's own directory; both may exist
+        dir += "/mpcx";
+        (void)mkdir(dir.c_str(), 0700);
+    }
     char name[96];
     snprintf(name, sizeof name, "/prg_%016llx_%016llx.ckpt", (unsigned long long)seed, (unsigned long long)lcg);
-    return std::string(dir) + name;
+    return dir + name;
+}
+// four interleaved multiply-xor lanes over the 64-bit words of the body (a serial chain would cost as much as the walk)
+u64 ckpt_checksum(const PrgCk *v, u64 count) {
+    const u64 *w = (const u64 *)v;
+    const u64 nw = count * (sizeof(PrgCk) / 8);
+    u64 h[4] = {0x243F6A8885A308D3ull, 0x13198A2E03707344ull, 0xA4093822299F31D0ull, 0x082EFA98EC4E6C89ull};
+    u64 i = 0;
+    for (; i + 4 <= nw; i += 4)
+        for (int k = 0; k < 4; k++) {
+            h[k] = (h[k] ^ w[i + k]) * 0x9E3779B97F4A7C15ull;
+            h[k] ^= h[k] >> 29;
+        }
+    for (; i < nw; i++) h[0] = ((h[0] ^ w[i]) * 0x9E3779B97F4A7C15ull) ^ (h[0] >> 31);
+    return (h[0] * 3 + h[1] * 5 + h[2] * 7 + h[3] * 11) ^ nw;
 }
 void ckpt_load(Table &T, u64 seed, u64 lcg) {
     const std::string path = ckpt_path(seed, lcg);
-    if (path.empty()) return;
+    if (path.empty() || T.host.empty()) return;
+    struct stat st;
+    if (stat(path.c_str(), &st) != 0 || !S_ISREG(st.st_mode)) return;
+    // the file this table last looked at (same length and modification time): nothing new in it
+    if ((u64)st.st_size == T.disk_seen_size && (u64)st.st_mtime == T.disk_seen_mtime) return;
+    T.disk_seen_size = (u64)st.st_size;
+    T.disk_seen_mtime = (u64)st.st_mtime;
     FILE *f = fopen(path.c_str(), "rb");
     if (!f) return;
-    u64 hdr[4];
-    if (fread(hdr, 8, 4, f) == 4 && hdr[0] == CKPT_MAGIC && hdr[1] == seed && hdr[2] == lcg && hdr[3] > T.host.size() &&
-        hdr[3] < (1ull << 36)) {
-        std::vector<PrgCk> v(hdr[3]);
-        // a file that another process is replacing is complete or absent (rename); a short read is ignored
-        if (fread(v.data(), sizeof(PrgCk), hdr[3], f) == hdr[3] && !T.host.empty() && v[0].seed == T.host[0].seed &&
-            v[0].lcg == T.host[0].lcg && v[0].hash == T.host[0].hash) {
-            T.host.swap(v);
-            T.loaded_from_disk = T.saved_to_disk = T.host.size();
+    u64 hdr[5];
+    const bool hdr_ok = fread(hdr, 8, 5, f) == 5 && hdr[0] == CKPT_MAGIC && hdr[1] == seed && hdr[2] == lcg &&
+                        hdr[3] > T.host.size() && hdr[3] < (1ull << 36) &&
+                        (u64)st.st_size == CKPT_HDR_BYTES + hdr[3] * sizeof(PrgCk);
+    if (hdr_ok) {
+        try {
+            std::vector<PrgCk> v(hdr[3]);
+            // a file that another process is replacing is complete or absent (rename); a short read is ignored
+            bool ok = fread(v.data(), sizeof(PrgCk), hdr[3], f) == hdr[3] && v[0].seed == T.host[0].seed &&
+                      v[0].lcg == T.host[0].lcg && v[0].hash == T.host[0].hash && ckpt_checksum(v.data(), hdr[3]) == hdr[4];
+            if (ok && hdr[3] >= 2) {
+                PrgCk c = v[hdr[3] - 2];
+                for (u64 i = 0; i < PRG_CK; i++) prv_step(c.seed, c.lcg, c.hash);
+                const PrgCk &l = v[hdr[3] - 1];
+                ok = c.seed == l.seed && c.lcg == l.lcg && c.hash == l.hash;
+            }
+            if (ok) {
+                T.host.swap(v);
+                T.loaded_from_disk = T.saved_to_disk = T.host.size();
+            }
+        } catch (const std::exception &) { // no memory for a table of that size: walk instead
         }
     }
     fclose(f);
@@ -102,8 +156,8 @@ void ckpt_save(Table &T, u64 seed, u64 lcg) {
     const std::string tpath = path + tmp;
     FILE *f = fopen(tpath.c_str(), "wb");
     if (!f) return;
-    const u64 hdr[4] = {CKPT_MAGIC, seed, lcg, (u64)T.host.size()};
-    const bool ok = fwrite(hdr, 8, 4, f) == 4 && fwrite(T.host.data(), sizeof(PrgCk), T.host.size(), f) == T.host.size();
+    const u64 hdr[5] = {CKPT_MAGIC, seed, lcg, (u64)T.host.size(), ckpt_checksum(T.host.data(), T.host.size())};
+    const bool ok = fwrite(hdr, 8, 5, f) == 5 && fwrite(T.host.data(), sizeof(PrgCk), T.host.size(), f) == T.host.size();
     if (fclose(f) == 0 && ok && rename(tpath.c_str(), path.c_str()) == 0)
         T.saved_to_disk = T.host.size();
     else
@@ -164,16 +218,31 @@ void walker_main() {
             R.walker_busy = true;
         }
         Table &T = *job.first;
-        if (hipSetDevice(job.second.device) != hipSuccess) continue;
+        // a job that is dropped (the device cannot be made current, or the process is ending) hands the table back:
+        // with bg_target left above the table's size, walk_ahead would take the job for still running and never
+        // queue another one
+        auto drop = [&] {
+            std::lock_guard<std::mutex> g(T.mu);
+            T.bg_target = T.host.size();
+            T.job_queued = false;
+        };
+        if (hipSetDevice(job.second.device) != hipSuccess) {
+            drop();
+            continue;
+        }
         for (;;) {
             {
                 std::lock_guard<std::mutex> lk(R.qmu);
-                if (R.stop) break;
+                if (R.stop) {
+                    drop();
+                    break;
+                }
             }
             std::lock_guard<std::mutex> g(T.mu);
             if (T.host.size() >= T.bg_target) {
                 (void)upload(T);
                 ckpt_save(T, job.second.seed, job.second.lcg);
+                T.job_queued = false;
                 break;
             }
             const u64 slice = T.host.size() + 32768; // ~2 M words, a few milliseconds
@@ -190,15 +259,20 @@ void walker_stop() {
     R.qcv.notify_all();
     R.qcv.wait(lk, [&] { return !R.walker_busy; });
 }
-void walk_ahead(Table &T, const Key &key, u64 target) { // T.mu held
+bool walker_enabled() {
     static const bool on = [] {
         const char *e = getenv("MPCX_PRG_WALK_AHEAD");
         return !(e && atoi(e) == 0);
     }();
-    if (!on || target <= T.bg_target || target <= T.host.size()) return;
-    const bool queued = T.bg_target > T.host.size(); // a job for this table is still running
-    T.bg_target = target;
-    if (queued) return;
+    return on;
+}
+// Asks the background thread to carry the table on to `target` checkpoints and then to mirror it on the device and
+// write it to the disk cache (T.mu held).  target = 0: only the mirroring and the write-back of what has been walked.
+void walk_ahead(Table &T, const Key &key, u64 target) {
+    if (!walker_enabled()) return;
+    if (target > T.bg_target) T.bg_target = target;
+    if (T.job_queued) return; // the running job reads bg_target under T.mu and goes on to it
+    if (target && target <= T.host.size()) return;
     Registry &R = reg();
     std::lock_guard<std::mutex> lk(R.qmu);
     if (R.stop) return;
@@ -207,6 +281,7 @@ void walk_ahead(Table &T, const Key &key, u64 target) { // T.mu held
         atexit(walker_stop);
         std::thread(walker_main).detach();
     }
+    T.job_queued = true;
     R.queue.emplace_back(&T, key);
     R.qcv.notify_one();
 }
@@ -299,7 +374,9 @@ __global__ __launch_bounds__(256) void prg_mod67_listed_kernel(const PrgCk *__re
 
 } // namespace
 
-int mpcx_prg_table(mpcx_ctx *ctx, u64 seed, u64 lcg, u64 t_end, const PrgCk **dev) {
+// save_now: write a table that grew back to the disk cache before returning (mpcx_prg_ckpt_build: another rank of
+// the node may be waiting for the file); otherwise the background thread writes it, off the caller's path
+static int prg_table(mpcx_ctx *ctx, u64 seed, u64 lcg, u64 t_end, const PrgCk **dev, bool save_now) {
     Table &T = table_of(ctx->device, seed, lcg);
     std::lock_guard<std::mutex> g(T.mu);
     if (T.host.empty()) {
@@ -316,8 +393,12 @@ int mpcx_prg_table(mpcx_ctx *ctx, u64 seed, u64 lcg, u64 t_end, const PrgCk **de
         u64 ahead = need / 8;
         ahead = ahead < 4096 ? 4096 : ahead > 65536 ? 65536 : ahead;
         walk_to(T, need + ahead);
-        ckpt_save(T, seed, lcg);
+        if (save_now || !walker_enabled())
+            ckpt_save(T, seed, lcg);
+        else
+            walk_ahead(T, Key{ctx->device, seed, lcg}, 0);
     }
+    if (save_now) ckpt_save(T, seed, lcg); // also what the background thread walked since the last write
     // The background walker keeps the table ahead of a stream that is being consumed: four times the step from the
     // previous request, within 16 Mi .. 256 Mi words, started when less than half of that is left.
     {
@@ -334,6 +415,9 @@ int mpcx_prg_table(mpcx_ctx *ctx, u64 seed, u64 lcg, u64 t_end, const PrgCk **de
     }
     *dev = T.dev;
     return 0;
+}
+int mpcx_prg_table(mpcx_ctx *ctx, u64 seed, u64 lcg, u64 t_end, const PrgCk **dev) {
+    return prg_table(ctx, seed, lcg, t_end, dev, false);
 }
 
 // the last context of a device has shut down: no kernel can read the superseded device copies any more
@@ -502,7 +586,7 @@ int mpcx_prg_ckpt_build(mpcx_ctx *ctx, uint64_t seed, uint64_t lcg, uint64_t n_p
     u64 t_end = 2 * n_buff;
     if (n_pops && PRG_POP_T0 + n_pops > t_end) t_end = PRG_POP_T0 + n_pops;
     const PrgCk *ck;
-    return mpcx_prg_table(ctx, seed, lcg, t_end, &ck);
+    return prg_table(ctx, seed, lcg, t_end, &ck, true);
 }
 
 int mpcx_prg_fill_buff(mpcx_ctx *ctx, uint64_t seed, uint64_t lcg, uint64_t first, uint64_t count, int64_t *ints,

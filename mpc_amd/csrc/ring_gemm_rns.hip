@@ -362,6 +362,14 @@ constexpr u32 TMW = 384, SKW = 2, MGRAN = 128;
 constexpr u32 KBW_BYTES = (TMW + TN) * RK;    // 20 KiB
 constexpr u32 STAGEW_BYTES = SKW * KBW_BYTES; // 40 KiB
 
+#ifdef MPCX_DEV_PROBES
+// Diagnostic build only (no stamp executes in the production library): per workgroup, the shader-clock ticks and the
+// 100 MHz reference ticks that pass between the first staged piece and the last MFMA of its tile.  Their ratio is the
+// clock the chip holds while the kernel runs.  Nothing in any kernel reads this array.
+constexpr u32 RNS_CLOCK_SLOTS = 8192;
+__device__ u64 rns_clock_probe[2 * RNS_CLOCK_SLOTS];
+#endif
+
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm" // m0 on a clobber list: nothing else in the kernel uses it
 template <u32 NPW>
@@ -417,6 +425,9 @@ __device__ __forceinline__ void rns_wide_tile(i8 *lds, const i8 *__restrict__ Ai
             for (int r = 0; r < 16; r++) acc[a][b][r] = 0;
 
     const u32 nst = nkb / SKW;
+#ifdef MPCX_DEV_PROBES
+    const u64 stamp_clk0 = __builtin_amdgcn_s_memtime(), stamp_ref0 = __builtin_amdgcn_s_memrealtime();
+#endif
 #pragma unroll
     for (u32 q = 0; q < NPW; q++) stage_piece(0, q);
     if (nst > 1) {
@@ -517,6 +528,15 @@ __device__ __forceinline__ void rns_wide_tile(i8 *lds, const i8 *__restrict__ Ai
     }
     tail();
 #undef MPCX_PIN
+#ifdef MPCX_DEV_PROBES
+    {
+        const u64 stamp_clk1 = __builtin_amdgcn_s_memtime(), stamp_ref1 = __builtin_amdgcn_s_memrealtime();
+        if (tid == 0 && blockIdx.x < RNS_CLOCK_SLOTS) {
+            rns_clock_probe[2 * blockIdx.x] = stamp_clk1 - stamp_clk0;
+            rns_clock_probe[2 * blockIdx.x + 1] = stamp_ref1 - stamp_ref0;
+        }
+    }
+#endif
 
     // epilogue: acc mod m, times inv, mod m -> one byte
 #pragma unroll
@@ -762,3 +782,15 @@ int ring_gemm_parts_rns(mpcx_ctx *ctx, const GemmPart *parts, int nparts, u64 r,
     MPCX_LAUNCH_CHECK();
     return 0;
 }
+
+#ifdef MPCX_DEV_PROBES
+// host side of the clock probe: copies the first `slots` (shader ticks, reference ticks) pairs of the last launches
+extern "C" int mpcx_dev_rns_clock_read(uint64_t *out, uint64_t slots) {
+    if (!out || slots > RNS_CLOCK_SLOTS) return 1;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(rns_clock_probe), 2 * slots * sizeof(u64)) == hipSuccess ? 0 : 1;
+}
+extern "C" int mpcx_dev_rns_clock_clear(void) {
+    static u64 zeros[2 * RNS_CLOCK_SLOTS];
+    return hipMemcpyToSymbol(HIP_SYMBOL(rns_clock_probe), zeros, sizeof zeros) == hipSuccess ? 0 : 1;
+}
+#endif

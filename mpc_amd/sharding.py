@@ -14,17 +14,18 @@ Nothing here touches a GPU.  Two kinds of work shard naturally (no exchange insi
 
 def split_range(total, parts, part, granule=1):
     """Contiguous, balanced split of range(total) into `parts`, in multiples of `granule`; returns (first, count) of
-    `part`.  The arithmetic is the library's own planner (mpcx_plan_split), the one the C++ engines and the group
-    entry points use, so that every layer cuts a vector in the same places."""
-    import ctypes
-
-    from .lib import load_library
-    first, count = ctypes.c_uint64(), ctypes.c_uint64()
-    rc = load_library().mpcx_plan_split(ctypes.c_uint64(total), ctypes.c_int(parts), ctypes.c_int(part),
-                                        ctypes.c_uint64(granule), ctypes.byref(first), ctypes.byref(count))
-    if rc:
+    `part`.  The first parts take one granule more when the granules do not divide evenly; the last part ends at
+    `total`.  Plain arithmetic, no library and no GPU: the library's planner (mpcx_plan_split, used by the C++ engines
+    and the group entry points) cuts in the same places, which a GPU-tier test checks over a grid of arguments."""
+    granule = max(int(granule), 1)
+    if parts < 1 or not 0 <= part < parts or total < 0:
         raise ValueError(f"split_range({total}, {parts}, {part}, {granule}): bad arguments")
-    return first.value, count.value
+    units = -(-total // granule)
+    base, rem = divmod(units, parts)
+    u0 = part * base + min(part, rem)
+    un = base + (1 if part < rem else 0)
+    first, end = min(u0 * granule, total), min((u0 + un) * granule, total)
+    return first, end - first
 
 
 def matmul_row_block(r_total, world, rank):

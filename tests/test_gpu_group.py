@@ -206,9 +206,39 @@ def test_checkpoint_tables_are_shared_through_the_disk_cache(tmp_path):
     third = run(env)
     assert third.returncode == 0 and third.stdout == first.stdout
     assert files[0].stat().st_size == len(data)
-    files[0].write_bytes(data[:32] + bytes(len(data) - 32))  # right header, wrong states: rejected by the first entry
+    files[0].write_bytes(data[:40] + bytes(len(data) - 40))  # right header, wrong states: rejected
     fourth = run(env)
     assert fourth.returncode == 0 and fourth.stdout == first.stdout
+    assert files[0].read_bytes() == data  # ... and replaced by the table walked again
+    # one state damaged far behind the first entry, exactly where the words asked for are replayed from: the checksum
+    # of the body rejects the file (accepted, it would give other words)
+    at = 40 + 24 * ((320005 + 3_000_000) // 64) + 3
+    files[0].write_bytes(data[:at] + bytes([data[at] ^ 0x10]) + data[at + 1:])
+    fifth = run(env)
+    assert fifth.returncode == 0 and fifth.stdout == first.stdout
+    # a header that promises 2^35 entries: the length of the file does not match, nothing is allocated for it
+    files[0].write_bytes(data[:24] + (1 << 35).to_bytes(8, "little") + data[32:])
+    sixth = run(env)
+    assert sixth.returncode == 0 and sixth.stdout == first.stdout
+
+
+def test_checkpoint_cache_default_directory(tmp_path):
+    """Without MPCX_CKPT_CACHE the tables go to $XDG_CACHE_HOME/mpcx (the directory is created); an empty
+    MPCX_CKPT_CACHE switches the cache off."""
+    import sys
+    prog = ("import sys, numpy as np; sys.path.insert(0, %r); from mpc_amd import Context; c = Context(0); "
+            "c.call('prg_ckpt_build', 0x78, 0, 2_000_000, 0); c.sync()" % ROOT)
+    env = {k: v for k, v in os.environ.items() if k != "MPCX_CKPT_CACHE"}
+    env["XDG_CACHE_HOME"] = str(tmp_path / "xdg")
+    os.makedirs(env["XDG_CACHE_HOME"])
+    r = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(list((tmp_path / "xdg" / "mpcx").glob("prg_*.ckpt"))) == 1
+    env["XDG_CACHE_HOME"] = str(tmp_path / "xdg2")
+    os.makedirs(env["XDG_CACHE_HOME"])
+    r = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=300,
+                       env=dict(env, MPCX_CKPT_CACHE=""))
+    assert r.returncode == 0 and not (tmp_path / "xdg2" / "mpcx").exists()
 
 
 @pytest.mark.parametrize("nbytes", [1, 4095, (4 << 20) - 1, 4 << 20, (4 << 20) + 1, (12 << 20) - 3, (37 << 20) + 5])
