@@ -66,8 +66,10 @@ class TableBuilder:
         self.made_dir = None
         if self.shared:
             if "MPCX_CKPT_CACHE" not in os.environ:  # a directory of this job's own, removed when the job ends
-                self.made_dir = os.path.join(os.environ.get("TMPDIR", "/tmp"),
-                                             "mpcx_ckpt_%s" % os.environ.get("MASTER_PORT", "0"))
+                import tempfile
+                box = [tempfile.mkdtemp(prefix="mpcx_ckpt_") if rank == 0 else None]
+                dist.broadcast_object_list(box, src=0)
+                self.made_dir = box[0]
                 os.environ["MPCX_CKPT_CACHE"] = self.made_dir
             os.makedirs(os.environ["MPCX_CKPT_CACHE"], exist_ok=True)
 
@@ -546,6 +548,402 @@ def merge_bitwise(per_rank):
     return out
 
 
+
+# ---------------------------------------------------------------------------------------------------------------
+# The other configurations of the metric, measured after the headline outside its timed region (rank 0, one GPU)
+MLP_DIMS = [(128, 784, 128), (128, 128, 128), (128, 128, 10)]
+
+
+def _mlp_plain(X, Ws):
+    """The plaintext 784-128-128-10 network with the fixed-point rule of the share-local rescale."""
+    h = X.reshape(128, 784)
+    for li, (_, l, c) in enumerate(MLP_DIMS):
+        h = (h @ Ws[li].reshape(l, c)) >> 16
+        if li < 2:
+            h = np.maximum(h, 0)
+    return h
+
+
+def _mlp_forward(pr, be, w, act, Wsh, op):
+    """Per layer matrix_mul -> local >> 16 on each share -> msb -> vector_mul(a, msb) -> a - that, no ReLU after the
+    last layer (benchmark/benchmark1.cpp:104-136); op(layer, name, fn) runs and times one operator."""
+    for li, (r, l, c) in enumerate(MLP_DIMS):
+        Z = op(li, "matrix_mul", lambda: pr.snn_matmul(w, act, Wsh[li], r, l, c))
+        a = op(li, "shift16", lambda: [be.ring_sar(Z[0], 16), be.ring_sar(Z[1], 16)])
+        if li < 2:
+            m = op(li, "msb", lambda: pr.snn_msb(w, a))
+            am = op(li, "vector_mul", lambda: pr.snn_vecmul(w, a, m))
+            a = op(li, "subtract", lambda: [be.ring_sub(a[j], am[j]) for j in range(2)])
+        act = a
+    return act
+
+
+def config4_mlp(ctx, torch, dev, reps=5):
+    """BASELINE configs[3]: the SecureNN 784-128-128-10 MLP at batch 128 (input and W1..W3 = PRgenerator(24,0)
+    .pop_int64() >> 48 in that order), all three roles on this GPU, every share and message resident: end-to-end latency
+    of the three layers (wall clock between two device synchronisations; the input and the weights are shared before)
+    and the device time per layer and operator."""
+    import copy
+
+    import mpc_amd.protocols as pr
+    from mpc_amd.backends import ResidentBackend
+    be = ResidentBackend(ctx, torch, dev)
+    total = 128 * 784 + sum(l * c for _, l, c in MLP_DIMS)
+    TableBuilder(ctx, None, 0, 1).build([(24, total, 0), (KEYS, 0, 5 * 128 * 784 * 128)])
+    words = torch.empty(total, dtype=torch.int64, device=dev)
+    ctx.call("prg_fill_pop", 24, 0, 0, total, words)
+    words >>= 48
+    X, off, Ws = words[:128 * 784].clone(), 128 * 784, []
+    for _, l, c in MLP_DIMS:
+        Ws.append(words[off:off + l * c].clone())
+        off += l * c
+    w = pr.World(be, record=False)
+    act0 = pr.snn_share(w, ctx.wrap(X, np.int64), X.numel())[:2]
+    Wsh = [pr.snn_share(w, ctx.wrap(Ws[li], np.int64), Ws[li].numel())[:2] for li in range(3)]
+    pops0 = copy.deepcopy(w.pops)
+    plain = lambda layer, name, fn: fn()
+    ctx.call("set_rand_cache", 4 << 30)
+    for _ in range(2):  # warm-up: tables, byte cache, allocator
+        w.pops = copy.deepcopy(pops0)
+        out = _mlp_forward(pr, be, w, act0, Wsh, plain)
+    lat = []
+    for _ in range(reps):
+        w.pops = copy.deepcopy(pops0)
+        dt, out = _timed(torch, lambda: _mlp_forward(pr, be, w, act0, Wsh, plain))
+        lat.append(dt * 1e3)
+    ops = []
+
+    def timed_op(layer, name, fn):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = fn()
+        e1.record()
+        ops.append((layer, name, e0, e1))
+        return r
+
+    w.pops = copy.deepcopy(pops0)
+    out = _mlp_forward(pr, be, w, act0, Wsh, timed_op)
+    torch.cuda.synchronize()
+    per_op = {}
+    for layer, name, e0, e1 in ops:
+        per_op.setdefault(f"layer{layer + 1}", {})[name] = round(e0.elapsed_time(e1), 4)
+    got = (be.down(out[0]) + be.down(out[1])).reshape(128, 10)
+    want = _mlp_plain(X.cpu().numpy(), [t.cpu().numpy() for t in Ws])
+    assert np.abs(got - want).max() <= 64, "config 4: the revealed output differs from the plaintext network"
+    lat.sort()
+    return {"workload": "SecureNN MLP 784-128-128-10, batch 128, Q16 inputs from PRgenerator(24,0); per layer matrix_mul, "
+                        ">>16, msb, vector_mul, subtract; 3 roles on one GPU, shares and messages resident",
+            "latency_ms": round(lat[len(lat) // 2], 3), "latency_ms_min": round(lat[0], 3), "reps": reps,
+            "device_ms_per_op": per_op,
+            "device_ms_by_op": {k: round(sum(v.get(k, 0.0) for v in per_op.values()), 4)
+                                for k in ("matrix_mul", "shift16", "msb", "vector_mul", "subtract")},
+            "verified": "revealed output within 64 units of the plaintext network (one unit per share-local shift)"}
+
+
+def cpu_mlp():
+    """The CPU oracle on configuration 4: one thread plays the three roles in turn, as config4_mlp does on the GPU."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))  # the oracle backend is test infrastructure: cpu_baseline leg only
+    import mpc_amd.protocols as pr
+    from backends import OracleBackend
+    orc = OracleBackend()
+    total = 128 * 784 + sum(l * c for _, l, c in MLP_DIMS)
+    words = orc.prg_fill_pop(24, 0, total) >> 48
+    X, off, Ws = words[:128 * 784].copy(), 128 * 784, []
+    for _, l, c in MLP_DIMS:
+        Ws.append(words[off:off + l * c].copy())
+        off += l * c
+    w = pr.World(orc, record=False)
+    act0 = pr.snn_share(w, X, X.size)[:2]
+    Wsh = [pr.snn_share(w, Ws[li], Ws[li].size)[:2] for li in range(3)]
+    t0 = time.perf_counter()
+    out = _mlp_forward(pr, orc, w, act0, Wsh, lambda layer, name, fn: fn())
+    dt = time.perf_counter() - t0
+    assert np.abs((out[0] + out[1]).reshape(128, 10) - _mlp_plain(X, Ws)).max() <= 64
+    return {"value": round(dt * 1e3, 2), "unit": "ms latency", "cores": 1, "kind": "port",
+            "sample": "the whole configuration (batch 128), three roles in turn on one thread"}
+
+
+def config5_slice(ctx, torch, dev):
+    """BASELINE configs[4] on one GPU: (a) the row block one of eight GPUs owns of the 16384 x 16384 ABY3 share matmul
+    (rows [0, 2048) of X, Y replicated: 2048 x 16384 . 16384 x 16384, four accumulation chunks per product; X and Y from
+    PRgenerator(20,0), shared by share_matrix on the device; party 0's matrix_mul segment); (b) the ReLU chain
+    add_prepare -> msb -> bit_inject -> subtract on 2^28 elements from PRgenerator(21,0), as sixteen element ranges of
+    2^24 (n_total = 2^28, i0 = 2^24 b): the documented batch schedule; all three parties on this GPU."""
+    import mpc_amd.protocols as pr
+    from mpc_amd.backends import ResidentBackend
+    full, rows, row0 = 16384, 2048, 0
+    l = c = full
+    plan = aby3_matmul_pop_plan(full, l, c)
+    nt, n = 1 << 28, 1 << 24
+    t0 = time.perf_counter()
+    TableBuilder(ctx, None, 0, 1).build([(KEY01, max(plan["matmul"] + rows * c, 7 * nt), 0), (KEY20, max(plan["matmul"] + rows * c, 7 * nt), 0),
+                                         (KEY12, max(plan["matmul"], 7 * nt), 0), (20, full * l + l * c, 0), (21, nt, 0)])
+    out = {"ckpt_build_s": round(time.perf_counter() - t0, 2)}
+    e = lambda k: torch.empty(k, dtype=torch.int64, device=dev)
+    X, Y = e(rows * l), e(l * c)
+    ctx.call("prg_fill_pop", 20, 0, row0 * l, rows * l, X)
+    ctx.call("prg_fill_pop", 20, 0, full * l, l * c, Y)
+    RX, RY = [e(rows * l), e(rows * l)], [e(l * c), e(l * c)]
+    for j in range(2):  # parties 0 and 1: party 0's product reads both
+        sn, sp = pair_seed(j, (j + 1) % 3), pair_seed(j, (j + 2) % 3)
+        ctx.call("aby3_share_local", X if j == 0 else None, rows * l, sn, row0 * l, sp, row0 * l, RX[j])
+        ctx.call("aby3_share_local", Y if j == 0 else None, l * c, sn, plan["share_y"], sp, plan["share_y"], RY[j])
+    del X, Y
+    Z = e(rows * c)
+    call = lambda: ctx.call("aby3_matmul_local_rows", RX[0], RX[1], RY[0], RY[1], rows, l, c, row0, KEY01, plan["matmul"],
+                            KEY20, plan["matmul"], Z)
+    call()
+    torch.cuda.synchronize()
+    reps = 3
+    ctx.call("profile", 1)
+    dt, _ = _timed(torch, call, reps=reps)
+    gemm_ms, gemm_cnt = prof_read(ctx, "limb_gemm")
+    split_ms, _ = prof_read(ctx, "split_limbs")
+    ctx.call("profile", 0)
+    import mpc_amd
+    lib = mpc_amd.load_library()
+    dims = (ctypes.c_uint64(rows), ctypes.c_uint64(2 * l), ctypes.c_uint64(c))
+    nprod = lib.mpcx_ring_gemm_products(*dims)
+    lib.mpcx_ring_gemm_kernel_name.restype = ctypes.c_char_p
+    ops = 36 * 2 * rows * c * (2 * l)  # algorithmic int8 operations of the block's product
+    alg = ops * reps / (gemm_ms * 1e-3) / 1e12
+    # the product without its mask passes a Freivalds check: P v = X0 ((Y0 + Y1) v) + X1 (Y0 v) over Z_2^64
+    ma, mb = e(rows * c), e(rows * c)
+    ctx.call("prg_fill_pop", KEY01, 0, plan["matmul"] + row0 * c, rows * c, ma)
+    ctx.call("prg_fill_pop", KEY20, 0, plan["matmul"] + row0 * c, rows * c, mb)
+    torch.cuda.synchronize()
+    P = (Z - (ma - mb)).view(rows, c)
+    del ma, mb
+    matvec = lambda M, v: (M * v.unsqueeze(0)).sum(1)  # int64 arithmetic on the device wraps mod 2^64
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    v = torch.randint(-2 ** 63, 2 ** 63 - 1, (c,), dtype=torch.int64, device=dev, generator=g) | 1
+    ysv = matvec(RY[0].view(l, c), v) + matvec(RY[1].view(l, c), v)
+    y0v = matvec(RY[0].view(l, c), v)
+    assert torch.equal(matvec(P, v), matvec(RX[0].view(rows, l), ysv) + matvec(RX[1].view(rows, l), y0v)), \
+        "config 5 row block: P v != X0 ((Y0 + Y1) v) + X1 (Y0 v)"
+    del P, RX, RY, Z, ysv, y0v
+    torch.cuda.empty_cache()
+    out["matmul_row_block"] = {
+        "shape": f"{rows}x{l} . {l}x{c} (rows [{row0}, {row0 + rows}) of {full}), one party's matrix_mul segment",
+        "ms": round(dt * 1e3, 3), "gemm_ms": round(gemm_ms / reps, 3), "split_combine_ms": round(split_ms / reps, 3),
+        "gemm_launches_per_call": gemm_cnt // reps, "kernel": lib.mpcx_ring_gemm_kernel_name(*dims).decode(),
+        "algorithmic_TOPs": round(alg, 1), "frac": round(alg / INT8_PEAK_TOPS, 4),
+        "issued_frac": round(alg * nprod / 36 / INT8_PEAK_TOPS, 4),
+        "call_frac": round(ops / dt / 1e12 / INT8_PEAK_TOPS, 4),
+        "ring_Gops": round(3 * 2 * rows * l * c / dt / 1e9, 1), "verified": "Freivalds check of the unmasked block"}
+
+    be = ResidentBackend(ctx, torch, dev)
+    x = torch.empty(n, dtype=torch.int64, device=dev)
+    T = be.tensor
+    spent, per_batch = 0.0, []
+    for b in range(nt // n):
+        i0 = b * n
+        ctx.call("prg_fill_pop", 21, 0, i0, n, x)
+        xD = ctx.wrap(x, np.int64)
+
+        def chain():
+            w = pr.World(be, record=False, n_total=nt, i0=i0)
+            Xs = pr.aby3_share(w, xD, n)
+            Gs, Ps = pr.aby3_add_prepare(w, Xs)
+            Zb = pr.aby3_msb(w, Gs, Ps)
+            return pr.aby3_bit_inject(w, Xs, Zb, minuend=Xs)
+
+        if b == 0:
+            chain()  # warm-up of the allocator
+        dt, R = _timed(torch, chain)
+        spent += dt
+        per_batch.append(round(dt * 1e3, 3))
+        relu = T(R[0][0]) + T(R[1][0]) + T(R[2][0])
+        assert torch.equal(relu, torch.clamp(x, min=0)), f"config 5 ReLU chain: range {b} does not reveal max(x, 0)"
+        del R, relu
+    rate = nt / spent
+    out["relu_2_28"] = {"n": nt, "schedule": "16 element ranges of 2^24 (n_total = 2^28, i0 = 2^24 b), 3 parties on one GPU",
+                        "elems_per_s": rate, "ms_total": round(spent * 1e3, 2), "ms_per_range": per_batch,
+                        "GBps": round(3 * 380.0 * rate / 1e9, 1), "hbm_frac": round(3 * 380.0 * rate / 1e9 / HBM_PEAK_GBS, 4),
+                        "verified": "every range reveals max(x, 0)"}
+    return out
+
+
+def prg_rates(ctx, torch, dev, log2n=28):
+    """The generator kernel by itself: mpcx_prg_fill_pop of 2^28 words (8 bytes written per word), and the same
+    regeneration fused into a consumer (the ABY3 share mask pop(next) - pop(prev): two stream words per 8 bytes
+    written).  CPU beside it: the reference's own PRgenerator (oracle/_ref/libref_prg.so, built from
+    utils/PRgenerator.cpp) popping 2^27 words on one host core."""
+    n = 1 << log2n
+    t0 = time.perf_counter()
+    TableBuilder(ctx, None, 0, 1).build([(KEY01, n, 0), (KEY20, n, 0)])
+    out = {"words": n, "ckpt_build_s": round(time.perf_counter() - t0, 2)}
+    buf = torch.empty(n, dtype=torch.int64, device=dev)
+    ctx.call("prg_fill_pop", KEY01, 0, 0, n, buf)
+    dt, _ = _timed(torch, lambda: ctx.call("prg_fill_pop", KEY01, 0, 0, n, buf), reps=3)
+    out["fill_words_per_s"] = n / dt
+    out["fill_GBps"] = round(8 * n / dt / 1e9, 1)
+    out["fill_hbm_frac"] = round(8 * n / dt / 1e9 / HBM_PEAK_GBS, 4)
+    ctx.call("aby3_share_local", None, n, KEY01, 0, KEY20, 0, buf)
+    dt, _ = _timed(torch, lambda: ctx.call("aby3_share_local", None, n, KEY01, 0, KEY20, 0, buf), reps=3)
+    out["fused_words_per_s"] = 2 * n / dt
+    out["fused_GBps_written"] = round(8 * n / dt / 1e9, 1)
+    # known answer: the first pops of the KEY01 stream (utils/PRgenerator.cpp:34-37)
+    ctx.call("prg_fill_pop", KEY01, 0, 0, n, buf)
+    first = [int(v) & (2 ** 64 - 1) for v in buf[:3].cpu().tolist()]
+    assert first == [0x2643CB33EC326FF6, 0x98BEFDA8E0849415, 0x64A5D429C2A35948], "PRG known-answer words differ"
+    return out
+
+
+def cpu_prg(log2n=27):
+    ref = os.path.join(ROOT, "oracle", "_ref", "libref_prg.so")
+    if not os.path.exists(ref):
+        return None
+    lib = ctypes.CDLL(ref)
+    n = 1 << log2n
+    out = np.empty(n, dtype=np.int64)
+    t0 = time.perf_counter()
+    lib.ref_prg_pop(ctypes.c_uint64(KEY01), ctypes.c_uint64(0), ctypes.c_uint64(0), ctypes.c_uint64(n),
+                    ctypes.c_void_p(out.ctypes.data))
+    dt = time.perf_counter() - t0
+    assert int(out[0]) & (2 ** 64 - 1) == 0x2643CB33EC326FF6
+    return {"value": n / dt, "unit": "words/s", "cores": 1, "kind": "reference",
+            "sample": f"PRgenerator(0xAB01, 0) constructed and popped 2^{log2n} times (utils/PRgenerator.cpp), {dt:.2f} s"}
+
+
+def ckpt_cache_times():
+    """Wall time of building the checkpoint table of a 2^28-word stream in a fresh process: walked (no cache), and read
+    from the on-disk cache a previous process left."""
+    import subprocess
+    import tempfile
+    prog = ("import sys, time; sys.path.insert(0, %r); from mpc_amd import Context; c = Context(0); t0 = time.perf_counter(); "
+            "c.call('prg_ckpt_build', 0xAB01, 0, 1 << 28, 0); print('BUILD_S', time.perf_counter() - t0)" % ROOT)
+    out = {}
+    with tempfile.TemporaryDirectory(prefix="mpcx_ckpt_") as d:
+        for label in ("cold", "cached"):
+            r = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=300,
+                               env=dict(os.environ, MPCX_CKPT_CACHE=d))
+            got = [l for l in r.stdout.splitlines() if l.startswith("BUILD_S")]
+            if r.returncode or not got:
+                return {"error": (r.stderr or r.stdout)[-300:]}
+            out[label + "_s"] = round(float(got[0].split()[1]), 3)
+    out["what"] = "mpcx_prg_ckpt_build of a 2^28-word pop stream in a fresh process, MPCX_CKPT_CACHE empty / filled"
+    return out
+
+
+def host_engine_rates():
+    """The PCIe- and host-inclusive rates: the C++ drop-in engines (mpc_amd/host/benchmark1: three party threads over
+    InProcMessenger, std::string messages, host containers in and out of every method, one GPU shared by the parties)."""
+    import re
+    import subprocess
+    exe = os.path.join(ROOT, "mpc_amd", "host", "benchmark1")
+    if not os.path.exists(exe):
+        return {"error": "mpc_amd/host/benchmark1 is not built"}
+    runs = [("aby3_4096", ["--engine", "aby3", "--width", "4096", "--vec", "1048576", "--repeat", "3", "--no-mlp"]),
+            ("securenn_1024", ["--engine", "securenn", "--width", "1024", "--vec", "1048576", "--repeat", "3", "--no-mlp"]),
+            ("mlp", ["--engine", "securenn", "--mlp-only", "--repeat", "3"])]
+    out = {}
+    for tag, args in runs:
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=240)
+        except subprocess.TimeoutExpired:
+            out[tag] = {"error": "timeout"}
+            continue
+        if r.returncode != 0 or "all results verified" not in r.stdout:
+            out[tag] = {"error": (r.stdout + r.stderr)[-300:]}
+            continue
+        rec = {"wall_s": round(time.perf_counter() - t0, 1), "args": " ".join(args), "verified": True}
+        for line in r.stdout.splitlines():
+            if not line.startswith("RESULT\t"):
+                continue
+            f = line.split("\t")
+            key = re.sub(r"[^a-z0-9]+", "_", f[1].lower()).strip("_")
+            kv = dict(x.split("=", 1) for x in f[2:])
+            rec[key] = {"ms": float(kv["ms"])}
+            if "rate" in kv:
+                rec[key]["rate"] = float(kv["rate"])
+                rec[key]["unit"] = kv["unit"]
+            if "layers_ms" in kv:
+                rec[key]["layers_ms"] = [float(x) for x in kv["layers_ms"].split(",")]
+        out[tag] = rec
+    return out
+
+
+def config5_multi(ctx, torch, dev, dist, rank, world, tables, gather_to, host_gather, full=16384, log2nt=28):
+    """BASELINE configs[4] over the ranks of a node (strong scaling: the work is fixed, every rank takes 1 / world of it).
+    (a) ABY3 16384 x 16384 share matmul: rank g owns rows [16384 g / world, ...) of X, Y is replicated, every product
+    runs as four accumulation chunks, and the row blocks of each party's message are gathered to rank 0 over RCCL
+    exactly as in the headline job (verified the same way).  (b) The 2^28-element ReLU chain in the sixteen-range
+    schedule of 2^24 elements each: rank g runs ranges [16 g / world, 16 (g + 1) / world), all three parties on its GPU."""
+    import mpc_amd.protocols as pr
+    from mpc_amd.backends import ResidentBackend
+    out = {"scaling": "strong", "ranks": world}
+    job = Aby3MatmulJob(ctx, torch, dev, full, rank, world, host_gather=host_gather, rows=full // world, gather=True,
+                        gather_to=gather_to, tables=tables)
+
+    def barrier():
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    job.step()
+    job.drain()
+    barrier()
+    steps = 2
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        job.step()
+    job.drain()
+    barrier()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device=dev if not host_gather else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    job.verify()
+    ops_alg = 3 * 36 * 2 * full * full * (2 * full)  # three parties, one product of depth 2 l each
+    out["matmul"] = {"workload": f"ABY3 {full}x{full} . {full}x{full} share matmul + reconstruct, 3 parties per step, "
+                                 f"{full // world} rows per rank, Y replicated, 4 accumulation chunks, gather to "
+                                 + ("rank 0" if gather_to == "root" else "every rank"),
+                     "ms_per_step": round(dt / steps * 1e3, 2), "steps": steps,
+                     "ring_Gops": round(3 * 3 * 2 * full ** 3 / (dt / steps) / 1e9, 1),
+                     "algorithmic_TOPs_whole_job": round(ops_alg / (dt / steps) / 1e12, 1),
+                     "step_frac_of_peak": round(ops_alg / (dt / steps) / 1e12 / (INT8_PEAK_TOPS * world), 4)}
+    del job
+    torch.cuda.empty_cache()
+
+    be = ResidentBackend(ctx, torch, dev)
+    nt, nb = 1 << log2nt, 16
+    n = nt // nb
+    b0, cnt = split_range(nb, world, rank)
+    x = torch.empty(n, dtype=torch.int64, device=dev)
+    T = be.tensor
+    spent, ok = 0.0, True
+    for b in range(b0, b0 + cnt):
+        i0 = b * n
+        ctx.call("prg_fill_pop", 21, 0, i0, n, x)
+        xD = ctx.wrap(x, np.int64)
+
+        def chain():
+            w = pr.World(be, record=False, n_total=nt, i0=i0)
+            Xs = pr.aby3_share(w, xD, n)
+            Gs, Ps = pr.aby3_add_prepare(w, Xs)
+            Zb = pr.aby3_msb(w, Gs, Ps)
+            return pr.aby3_bit_inject(w, Xs, Zb, minuend=Xs)
+
+        if b == b0:
+            chain()
+        d, R = _timed(torch, chain)
+        spent += d
+        ok = ok and bool(torch.equal(T(R[0][0]) + T(R[1][0]) + T(R[2][0]), torch.clamp(x, min=0)))
+        del R
+    per_rank = [None] * world
+    dist.all_gather_object(per_rank, (spent, cnt * n, ok))
+    assert all(p[2] for p in per_rank), "config 5 ReLU chain: a range does not reveal max(x, 0)"
+    slowest = max(p[0] for p in per_rank)
+    rate = nt / slowest
+    out["relu_2_28"] = {"n": nt, "schedule": f"16 element ranges of 2^{log2nt - 4}, {nb / world:g} per rank",
+                        "elems_per_s": rate, "ms_slowest_rank": round(slowest * 1e3, 2),
+                        "hbm_frac_per_gpu": round(3 * 380.0 * rate / world / 1e9 / HBM_PEAK_GBS, 4),
+                        "verified": "every range reveals max(x, 0)"}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -554,6 +952,11 @@ def main():
     ap.add_argument("--size", type=int, default=4096, help="matrix dimension per GPU (rows of the row-block, l and c)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-bitwise", action="store_true")
+    ap.add_argument("--config5-size", type=int, default=16384, help="rehearsals: a smaller matrix for the multi-rank "
+                    "record of configuration 5")
+    ap.add_argument("--config5-log2n", type=int, default=28, help="rehearsals: a shorter vector for its ReLU chain")
+    ap.add_argument("--no-extras", action="store_true", help="skip the records of configurations 4 and 5, the generator "
+                    "rates and the host-engine rates")
     ap.add_argument("--no-verify", action="store_true", help="development only: skip the result check")
     ap.add_argument("--bitwise-log2n", type=int, default=24, help="elements of the privateCompare / msb / ReLU runs")
     ap.add_argument("--rows", type=int, default=0, help="rows of X per GPU when different from --size (a row block "
@@ -647,6 +1050,28 @@ def main():
         if dist is not None:  # no collective inside bitwise_rates: a rank that failed still arrives here
             bitwise = [None] * world
             dist.all_gather_object(bitwise, mine)
+    extras = {}
+    if not args.no_extras:
+        job = job.shape_only()
+        torch.cuda.empty_cache()
+        if world > 1:
+            c5, lg = args.config5_size, args.config5_log2n
+            tables.build([(k, max(3 * c5 * c5, 7 << lg), 0) for k in (KEY01, KEY12, KEY20)] + [(20, 2 * c5 * c5, 0), (21, 1 << lg, 0)])
+            extras["config5"] = config5_multi(ctx, torch, dev, dist, rank, world, tables, args.gather,
+                                              args.dist_backend == "gloo", full=c5, log2nt=lg)
+        else:
+            for key, fn in (("config4", lambda: config4_mlp(ctx, torch, dev)), ("prg", lambda: prg_rates(ctx, torch, dev)),
+                            ("config5_slice", lambda: config5_slice(ctx, torch, dev))):
+                try:
+                    extras[key] = fn()
+                except Exception as ex:  # a secondary record must not hide the headline number
+                    extras[key] = {"error": f"{type(ex).__name__}: {ex}"}
+                torch.cuda.empty_cache()
+            ctx.call("set_rand_cache", 0)  # the host engines below share this GPU
+            ctx.call("set_rand_cache", 4 << 30)
+            if not args.no_cpu:
+                extras["host_engine"] = host_engine_rates()
+                extras["ckpt_cache"] = ckpt_cache_times()
     if rank == 0:
         value = job.ring_ops_per_step() * args.steps / dt / 1e9
         # dominant kernel: the int8 MFMA GEMM.  Algorithmic work per product (the positional formulation the metric is
@@ -679,7 +1104,8 @@ def main():
                                    "inputs from PRgenerator(20,0)",
                        "rows_per_gpu": job.rows, "parallelism": f"row-block x{world}" if world > 1 else "single GPU"},
             "roofline": {"bound": "mfma", "kernel": kernel, "achieved": achieved, "peak": INT8_PEAK_TOPS,
-                         "unit": "TFLOP/s", "frac": achieved / INT8_PEAK_TOPS,
+                         "unit": "TOP/s", "frac": achieved / INT8_PEAK_TOPS,
+                         "step_frac": ops_per_product * 3 * args.steps / dt / 1e12 / (INT8_PEAK_TOPS * world),
                          "issued": issued, "issued_frac": issued / INT8_PEAK_TOPS, "int8_products_per_multiply_add": nprod,
                          "gemm_phase": phase, "gemm_phase_frac": phase / INT8_PEAK_TOPS,
                          "traffic": measured_traffic(args.size, world, kernel),
@@ -690,15 +1116,23 @@ def main():
                          "note": "achieved = algorithmic int8 TOP/s: 36 digit pairs x 2 x rows x c x 2l per product over the "
                                  "summed launch time of the GEMM kernel; issued = the int8 operations the kernel executes "
                                  "(18 residue products instead of 36 digit-pair products when the residue formulation runs); "
-                                 "gemm_phase = the same algorithmic work over operand split + GEMM + recombination"},
+                                 "gemm_phase = the same algorithmic work over operand split + GEMM + recombination; "
+                                 "step_frac = the algorithmic int8 operations of a whole step (3 products) over ms_per_step"},
             "kernel_ms_per_step": breakdown,
         }
         if bitwise is not None:
             res["bitwise"] = merge_bitwise(bitwise)
+        res.update(extras)
         if world == 1 and not args.no_cpu:
             res["cpu_baseline"] = cpu_baseline()
             if "bitwise" in res and "error" not in res["bitwise"]:
                 res["bitwise"]["cpu_baseline"] = cpu_bitwise()
+            if "config4" in res and "error" not in res["config4"]:
+                res["config4"]["cpu_baseline"] = cpu_mlp()
+                if "mlp" in res.get("host_engine", {}) and "bench_securenn_mlp" in res["host_engine"]["mlp"]:
+                    res["config4"]["host_latency_ms"] = res["host_engine"]["mlp"]["bench_securenn_mlp"]["ms"]
+            if "prg" in res and "error" not in res["prg"]:
+                res["prg"]["cpu_baseline"] = cpu_prg()
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()

@@ -7,7 +7,7 @@
 //   * without arguments the three parties run as three threads of this process over InProcMessenger (all on
 //     MPCX_DEVICE, default GPU 0); with a party id it is one party of a three-process run over SocketMessenger,
 //     as the reference driver is.
-// usage: benchmark1 [party_id] [--width W] [--vec N] [--repeat R] [--engine aby3|securenn|my] [--no-mlp]
+// usage: benchmark1 [party_id] [--width W] [--vec N] [--repeat R] [--engine aby3|securenn|my] [--no-mlp | --mlp-only]
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -24,7 +24,7 @@
 
 struct Options {
     size_t width = 200, vec = 0, repeat = 10;
-    bool mlp = true;
+    bool mlp = true, mlp_only = false;
     const char *engine = nullptr; // run only this engine's lines: "aby3", "securenn" or "my"
 };
 static std::atomic<int> failures{0};
@@ -44,6 +44,7 @@ static void report(size_t party, const char *what, double ms, double units, cons
     print_plus();
     printf("spent time: %.3f ms per repetition   (%.3g %s/s)\n", ms, units / (ms * 1e-3), unit);
     print_minus();
+    printf("RESULT\t%s\tms=%.4f\trate=%.6g\tunit=%s/s\n", what, ms, units / (ms * 1e-3), unit); // one line for scripts
     fflush(stdout);
 }
 
@@ -72,13 +73,24 @@ static void bench_aby3(VirtuleMessenger *messenger, size_t party, const Options 
         VecI64 T;
         engine.reveal(Tv, T);
         if (t == opt.repeat) { // check the last repetition: trunc may be one below the exact shift
-            MatrixXl Z = X * Y;
             size_t bad = 0;
-            for (size_t i = 0; i < w; i++)
-                for (size_t j = 0; j < w; j++) {
-                    const int64_t want = Z(i, j) >> 16, got = T[i * w + j];
+            if (w <= 1024) {
+                MatrixXl Z = X * Y;
+                for (size_t i = 0; i < w; i++)
+                    for (size_t j = 0; j < w; j++) {
+                        const int64_t want = Z(i, j) >> 16, got = T[i * w + j];
+                        bad += !(got == want || got == want - 1);
+                    }
+            } else { // the plain product of wide matrices would take a host core a minute: 4096 sampled entries
+                PRgenerator pick(0xC4EC, 0);
+                for (size_t s = 0; s < 4096; s++) {
+                    const size_t i = (uint64_t)pick.pop_int64() % w, j = (uint64_t)pick.pop_int64() % w;
+                    uint64_t dot = 0;
+                    for (size_t k = 0; k < w; k++) dot += (uint64_t)X(i, k) * (uint64_t)Y(k, j);
+                    const int64_t want = (int64_t)dot >> 16, got = T[i * w + j];
                     bad += !(got == want || got == want - 1);
                 }
+            }
             CHECK(bad == 0);
         }
     }
@@ -306,15 +318,19 @@ static void bench_mlp(VirtuleMessenger *messenger, size_t party, const Options &
         printf("latency: %.3f ms   layers: %.3f / %.3f / %.3f ms\n", total / reps, layer_ms[0] / reps, layer_ms[1] / reps,
                layer_ms[2] / reps);
         print_minus();
+        printf("RESULT\tbench_securenn MLP\tms=%.4f\tlayers_ms=%.4f,%.4f,%.4f\n", total / reps, layer_ms[0] / reps,
+               layer_ms[1] / reps, layer_ms[2] / reps);
         fflush(stdout);
     }
 }
 
 static void party_main(VirtuleMessenger *messenger, size_t party, const Options &opt) {
     const auto wanted = [&](const char *name) { return !opt.engine || !strcmp(opt.engine, name); };
-    if (wanted("aby3")) bench_aby3(messenger, party, opt);
-    if (wanted("securenn")) bench_securenn(messenger, party, opt);
-    if (wanted("my")) bench_me(messenger, party, opt);
+    if (!opt.mlp_only) {
+        if (wanted("aby3")) bench_aby3(messenger, party, opt);
+        if (wanted("securenn")) bench_securenn(messenger, party, opt);
+        if (wanted("my")) bench_me(messenger, party, opt);
+    }
     if (opt.mlp && wanted("securenn")) bench_mlp(messenger, party, opt);
 }
 
@@ -332,10 +348,12 @@ int main(int argc, char const *argv[]) {
             opt.engine = argv[++i];
         else if (!strcmp(argv[i], "--no-mlp"))
             opt.mlp = false;
+        else if (!strcmp(argv[i], "--mlp-only"))
+            opt.mlp_only = true;
         else if (argv[i][0] >= '0' && argv[i][0] <= '2' && argv[i][1] == 0)
             party = argv[i][0] - '0';
         else {
-            printf("usage:\nbenchmark1 [party_id in {0,1,2}] [--width W] [--vec N] [--repeat R] [--engine aby3|securenn|my] [--no-mlp]\n");
+            printf("usage:\nbenchmark1 [party_id in {0,1,2}] [--width W] [--vec N] [--repeat R] [--engine aby3|securenn|my] [--no-mlp | --mlp-only]\n");
             return 1;
         }
     }
