@@ -331,6 +331,33 @@ def _timed(torch, fn, reps=1):
     return (time.perf_counter() - t0) / reps, r
 
 
+def private_compare_inputs(ctx, torch, dev, i0, n):
+    """privateCompare inputs for elements [i0, i0 + n) as test/test_securenn.cpp:160-175 draws them from
+    PRgenerator(22,0), 67 pops per element: x, r (forced to -1 when i % 5 == 2), beta = the low bit of a pop, then for
+    every bit position k the share xs0[k] = (uint16)pop % 67 of party 0; party 1's share is
+    (bit_k(x) + 67 - xs0[k]) % 67.  Returns (xbits0, xbits1, beta, r) on the device."""
+    xb = torch.empty(64 * n, dtype=torch.int16, device=dev)
+    xb1 = torch.empty(64 * n, dtype=torch.int16, device=dev)
+    beta = torch.empty(n, dtype=torch.int8, device=dev)
+    r = torch.empty(n, dtype=torch.int64, device=dev)
+    step = 1 << 18
+    kk = torch.arange(64, device=dev)
+    for a in range(0, n, step):
+        m = min(step, n - a)
+        w = torch.empty(67 * m, dtype=torch.int64, device=dev)
+        ctx.call("prg_fill_pop", 22, 0, 67 * (i0 + a), 67 * m, w)
+        w = w.view(m, 67)
+        x = w[:, 0]
+        r[a:a + m] = w[:, 1]
+        beta[a:a + m] = (w[:, 2] & 1).to(torch.int8)
+        s0 = (w[:, 3:] & 0xFFFF) % 67
+        xb[64 * a:64 * (a + m)] = s0.to(torch.int16).reshape(-1)
+        xb1[64 * a:64 * (a + m)] = ((((x.unsqueeze(1) >> kk) & 1) + 67 - s0) % 67).to(torch.int16).reshape(-1)
+    idx = torch.arange(i0, i0 + n, device=dev)
+    r[idx % 5 == 2] = -1  # test/test_securenn.cpp:165-166
+    return xb, xb1, beta, r
+
+
 def bitwise_table_specs(log2n, world):
     """(seed, n_pops, n_buff) of every generator stream bitwise_rates reads: the SecureNN buffers of a 2^log2n-element
     vector, its inputs from PRgenerator(22,0), and the pop streams of the ABY3 chain on world * 2^log2n elements (share:
@@ -378,26 +405,7 @@ def bitwise_rates(ctx, torch, dev, log2n=24, rank=0, world=1, tables=None):
     # Inputs as test/test_securenn.cpp:160-175 draws them from PRgenerator(22,0), 67 pops per element: x, r (forced to
     # -1 when i % 5 == 2), beta = the low bit of a pop, then for every bit position k the share xs0[k] = (uint16)pop % 67
     # of party 0; party 1's share (bit_k(x) + 67 - xs0[k]) % 67 is what the party role of party 1 would be handed.
-    xb = torch.empty(64 * n, dtype=torch.int16, device=dev)
-    xb1 = torch.empty(64 * n, dtype=torch.int16, device=dev)
-    beta = torch.empty(n, dtype=torch.int8, device=dev)
-    r = torch.empty(n, dtype=torch.int64, device=dev)
-    step = 1 << 18
-    kk = torch.arange(64, device=dev)
-    for a in range(0, n, step):
-        m = min(step, n - a)
-        w = torch.empty(67 * m, dtype=torch.int64, device=dev)
-        ctx.call("prg_fill_pop", 22, 0, 67 * (i0 + a), 67 * m, w)
-        w = w.view(m, 67)
-        x = w[:, 0]
-        r[a:a + m] = w[:, 1]
-        beta[a:a + m] = (w[:, 2] & 1).to(torch.int8)
-        s0 = (w[:, 3:] & 0xFFFF) % 67
-        xb[64 * a:64 * (a + m)] = s0.to(torch.int16).reshape(-1)
-        xb1[64 * a:64 * (a + m)] = ((((x.unsqueeze(1) >> kk) & 1) + 67 - s0) % 67).to(torch.int16).reshape(-1)
-    idx = torch.arange(i0, i0 + n, device=dev)
-    r[idx % 5 == 2] = -1  # test/test_securenn.cpp:165-166
-    del w, x, s0, idx
+    xb, xb1, beta, r = private_compare_inputs(ctx, torch, dev, i0, n)
     d0 = torch.empty(64 * n, dtype=torch.int16, device=dev)
     d1 = torch.empty(64 * n, dtype=torch.int16, device=dev)
     b2 = torch.empty(n, dtype=torch.int8, device=dev)

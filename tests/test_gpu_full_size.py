@@ -51,34 +51,35 @@ def uless(torch, a, b):
 
 
 def test_private_compare_2_24(env):
-    """privateCompare on 2^24 elements (r = -1 on every fifth): beta xor beta' = (x > r) for every element."""
+    """privateCompare on 2^24 elements drawn as test/test_securenn.cpp:160-175 draws them from PRgenerator(22,0) (x, r,
+    beta, then the 64 Z_67 shares of party 0; r = -1 on every fifth element): beta xor beta' = (x > r) for every
+    element, with the byte cache on and with it off."""
     ctx, torch, dev, _ = env
+    from bench import private_compare_inputs
     n = 1 << 24
-    g = torch.Generator(device=dev)
-    g.manual_seed(22)
-    x = torch.randint(-2 ** 63, 2 ** 63 - 1, (n,), dtype=torch.int64, device=dev, generator=g)
-    r = torch.randint(-2 ** 63, 2 ** 63 - 1, (n,), dtype=torch.int64, device=dev, generator=g)
-    r[2::5] = -1
-    beta = torch.randint(0, 2, (n,), dtype=torch.int8, device=dev, generator=g)
-    s0 = torch.randint(0, 67, (n, 64), dtype=torch.int16, device=dev, generator=g)
-    s1 = torch.empty_like(s0)
-    k = torch.arange(64, device=dev)
-    step = 1 << 20
-    for a in range(0, n, step):  # bit k of x, shared over Z_67 (test/test_securenn.cpp:167-175)
-        bits = ((x[a:a + step].unsqueeze(1) >> k) & 1).to(torch.int16)
-        s1[a:a + step] = (bits + 67 - s0[a:a + step]) % 67
-    del bits
+    ctx.call("prg_ckpt_build", 22, 0, 67 * n, 0)
+    s0, s1, beta, r = private_compare_inputs(ctx, torch, dev, 0, n)
+    x = torch.empty(n, dtype=torch.int64, device=dev)
+    step = 1 << 18
+    for a in range(0, n, step):  # x = the first of an element's 67 pops
+        w = torch.empty(67 * step, dtype=torch.int64, device=dev)
+        ctx.call("prg_fill_pop", 22, 0, 67 * a, 67 * step, w)
+        x[a:a + step] = w.view(step, 67)[:, 0]
+    del w
+    assert int((r == -1).sum()) >= n // 5 and int(s0.max()) < 67 and int(s1.max()) < 67
     ctx.call("prg_ckpt_build", KEY01, 0, 0, 128 * n)
-    ctx.call("set_rand_cache", 4 << 30)
+    want = uless(torch, r, x).to(torch.int8)
     d0, d1 = torch.empty_like(s0), torch.empty_like(s0)
     b2 = torch.empty(n, dtype=torch.int8, device=dev)
-    ctx.call("snn_pc_party", 0, s0, beta, r, n, 0, n, KEY01, d0)
-    ctx.call("snn_pc_party", 1, s1, beta, r, n, 0, n, KEY01, d1)
-    ctx.call("snn_pc_helper", d0, d1, n, b2)
-    torch.cuda.synchronize()
-    assert int(d0.max()) < 67 and int(d1.max()) < 67 and int(d0.min()) >= 0
-    want = uless(torch, r, x).to(torch.int8)
-    assert torch.equal(beta ^ b2, want)
+    for cap in (4 << 30, 0):
+        ctx.call("set_rand_cache", cap)
+        ctx.call("snn_pc_party", 0, s0, beta, r, n, 0, n, KEY01, d0)
+        ctx.call("snn_pc_party", 1, s1, beta, r, n, 0, n, KEY01, d1)
+        ctx.call("snn_pc_helper", d0, d1, n, b2)
+        torch.cuda.synchronize()
+        assert int(d0.max()) < 67 and int(d1.max()) < 67 and int(d0.min()) >= 0
+        assert torch.equal(beta ^ b2, want), f"byte cache {cap}"
+    ctx.call("set_rand_cache", 4 << 30)
 
 
 def test_snn_msb_2_24(env):
