@@ -844,6 +844,7 @@ def host_engine_rates():
     if not os.path.exists(exe):
         return {"error": "mpc_amd/host/benchmark1 is not built"}
     runs = [("aby3_4096", ["--engine", "aby3", "--width", "4096", "--vec", "1048576", "--repeat", "3", "--no-mlp"]),
+            ("aby3_4096_second_operand_pinned", ["--engine", "aby3", "--width", "4096", "--vec", "4096", "--repeat", "3", "--no-mlp", "--pin"]),
             ("securenn_1024", ["--engine", "securenn", "--width", "1024", "--vec", "1048576", "--repeat", "3", "--no-mlp"]),
             ("mlp", ["--engine", "securenn", "--mlp-only", "--repeat", "3"])]
     out = {}

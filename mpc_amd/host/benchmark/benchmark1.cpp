@@ -7,7 +7,7 @@
 //   * without arguments the three parties run as three threads of this process over InProcMessenger (all on
 //     MPCX_DEVICE, default GPU 0); with a party id it is one party of a three-process run over SocketMessenger,
 //     as the reference driver is.
-// usage: benchmark1 [party_id] [--width W] [--vec N] [--repeat R] [--engine aby3|securenn|my] [--no-mlp | --mlp-only]
+// usage: benchmark1 [party_id] [--width W] [--vec N] [--repeat R] [--engine aby3|securenn|my] [--no-mlp | --mlp-only] [--pin]
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -25,6 +25,7 @@
 struct Options {
     size_t width = 200, vec = 0, repeat = 10;
     bool mlp = true, mlp_only = false;
+    bool pin = false; // keep the second operand of the matrix products (the "weights") on the device
     const char *engine = nullptr; // run only this engine's lines: "aby3", "securenn" or "my"
 };
 static std::atomic<int> failures{0};
@@ -63,12 +64,17 @@ static void bench_aby3(VirtuleMessenger *messenger, size_t party, const Options 
         array<MatrixXl, 2> Xj, Yj, Zj;
         engine.share_matrix(X, Xj);
         engine.share_matrix(Y, Yj);
+        if (opt.pin) engine.pin(Yj); // the second operand as a resident weight matrix
+        // the clock runs around the two engine calls only, as in the reference (benchmark/benchmark1.cpp:33-50)
         auto t0 = Clock::now();
         engine.matrix_mul(Xj, Yj, Zj);
+        double ms = ms_since(t0);
+        if (opt.pin) engine.unpin(Yj);
         array<VecI64, 2> Zv, Tv;
         for (size_t i = 0; i < 2; i++) matrix2vecI64(Zj[i], Zv[i]);
+        t0 = Clock::now();
         engine.trunc(Zv, Tv, 16);
-        const double ms = ms_since(t0);
+        ms += ms_since(t0);
         if (t) spent += ms;
         VecI64 T;
         engine.reveal(Tv, T);
@@ -117,6 +123,26 @@ static void bench_aby3(VirtuleMessenger *messenger, size_t party, const Options 
         }
     }
     report(party, "bench_aby3 msb & bit_inject", spent / opt.repeat, (double)vec_size, "elem");
+
+    // the same chain plus the subtraction as the engine's one relu protocol (an addition to the reference's surface)
+    spent = 0;
+    for (size_t t = 0; t <= opt.repeat; t++) {
+        VecI64 X(vec_size), R;
+        for (size_t i = 0; i < vec_size; i++) X[i] = rnd.pop_int64();
+        array<VecI64, 2> Xj, Rj;
+        engine.share(X, Xj);
+        auto t0 = Clock::now();
+        engine.relu(Xj, Rj);
+        const double ms = ms_since(t0);
+        if (t) spent += ms;
+        if (t == opt.repeat) {
+            engine.reveal(Rj, R);
+            size_t bad = 0;
+            for (size_t i = 0; i < vec_size; i++) bad += R[i] != (X[i] < 0 ? 0 : X[i]);
+            CHECK(bad == 0);
+        }
+    }
+    report(party, "bench_aby3 relu", spent / opt.repeat, (double)vec_size, "elem");
 }
 
 static void bench_securenn(VirtuleMessenger *messenger, size_t party, const Options &opt) {
@@ -135,11 +161,13 @@ static void bench_securenn(VirtuleMessenger *messenger, size_t party, const Opti
         MatrixXl Xj(w, w), Yj(w, w), Zj;
         vector2matrix(Xv, Xj);
         vector2matrix(Yv, Yj);
+        if (opt.pin) engine.pin(Yj);
         auto t0 = Clock::now();
         engine.matrix_mul(Xj, Yj, Zj);
         for (size_t i = 0; i < w; i++)
             for (size_t j = 0; j < w; j++) Zj(i, j) = Zj(i, j) >> 16; // benchmark/benchmark1.cpp:106-112
         const double ms = ms_since(t0);
+        if (opt.pin) engine.unpin(Yj);
         if (t) spent += ms;
         if (t == opt.repeat) {
             MatrixXl Z, X(w, w), Y(w, w);
@@ -178,6 +206,25 @@ static void bench_securenn(VirtuleMessenger *messenger, size_t party, const Opti
         }
     }
     report(party, "bench_securenn msb & vector_mul", spent / opt.repeat, (double)vec_size, "elem");
+
+    spent = 0;
+    for (size_t t = 0; t <= opt.repeat; t++) {
+        vector<int64_t> A(vec_size), Aj, Rj, R;
+        for (auto &a : A) a = rnd.pop_int64() / 2;
+        engine.share(A, Aj);
+        auto t0 = Clock::now();
+        engine.relu(Aj, Rj);
+        const double ms = ms_since(t0);
+        if (t) spent += ms;
+        if (t == opt.repeat) {
+            engine.reveal(Rj, R);
+            size_t bad = 0;
+            if (party != 2)
+                for (size_t i = 0; i < vec_size; i++) bad += R[i] != (A[i] < 0 ? 0 : A[i]);
+            CHECK(bad == 0);
+        }
+    }
+    report(party, "bench_securenn relu", spent / opt.repeat, (double)vec_size, "elem");
 }
 
 static void bench_me(VirtuleMessenger *messenger, size_t party, const Options &opt) {
@@ -242,13 +289,13 @@ static void snn_dense(SecurennEngine &engine, const MatrixXl &Xj, const MatrixXl
     MatrixXl Zj;
     engine.matrix_mul(Xj, Wj, Zj);
     const size_t r = Zj.rows(), c = Zj.cols();
-    vector<int64_t> a(r * c), m, am;
+    vector<int64_t> a(r * c);
     for (size_t i = 0; i < r; i++)
         for (size_t j = 0; j < c; j++) a[i * c + j] = Zj(i, j) >> 16;
     if (relu) {
-        engine.msb(a, m);
-        engine.vector_mul(a, m, am);
-        for (size_t i = 0; i < a.size(); i++) a[i] -= am[i];
+        vector<int64_t> r;
+        engine.relu(a, r); // = msb, vector_mul(a, msb), a - that (benchmark/benchmark1.cpp:135-136), as one protocol
+        a.swap(r);
     }
     out.resize(r, c);
     vector2matrix(a, out);
@@ -277,6 +324,7 @@ static void bench_mlp(VirtuleMessenger *messenger, size_t party, const Options &
     };
     share_matrix(X, Xj);
     for (int l = 0; l < 3; l++) share_matrix(W[l], Wj[l]);
+    for (int l = 0; l < 3; l++) engine.pin(Wj[l]); // the weights stay on the device for every pass
     double total = 0, layer_ms[3] = {0, 0, 0};
     MatrixXl act;
     const size_t reps = opt.repeat < 3 ? opt.repeat : 3;
@@ -291,6 +339,7 @@ static void bench_mlp(VirtuleMessenger *messenger, size_t party, const Options &
             if (t) layer_ms[l] += ms, total += ms;
         }
     }
+    for (int l = 0; l < 3; l++) engine.unpin(Wj[l]);
     MatrixXl out;
     engine.reveal_matrix(act, out);
     if (party != 2) {
@@ -350,10 +399,12 @@ int main(int argc, char const *argv[]) {
             opt.mlp = false;
         else if (!strcmp(argv[i], "--mlp-only"))
             opt.mlp_only = true;
+        else if (!strcmp(argv[i], "--pin"))
+            opt.pin = true;
         else if (argv[i][0] >= '0' && argv[i][0] <= '2' && argv[i][1] == 0)
             party = argv[i][0] - '0';
         else {
-            printf("usage:\nbenchmark1 [party_id in {0,1,2}] [--width W] [--vec N] [--repeat R] [--engine aby3|securenn|my] [--no-mlp | --mlp-only]\n");
+            printf("usage:\nbenchmark1 [party_id in {0,1,2}] [--width W] [--vec N] [--repeat R] [--engine aby3|securenn|my] [--no-mlp | --mlp-only] [--pin] [--pin]\n");
             return 1;
         }
     }

@@ -25,7 +25,37 @@ ABY3Engine::ABY3Engine(VirtuleMessenger *_messenger, size_t _party_id) : messeng
     gpu = group ? mpcx_group_ctx(group, 0) : mpcgpu::open_context();
 }
 
+// a share pair kept on the engine's first GPU, column-major as Eigen stores it
+struct ABY3Engine::Pinned {
+    const MatPair *key;
+    size_t rows, cols;
+    Dev<int64_t> s0, s1;
+    Pinned(mpcx_ctx *ctx, const MatPair &M)
+        : key(&M), rows(M[0].rows()), cols(M[0].cols()), s0(ctx, M[0].data(), M[0].rows() * M[0].cols()),
+          s1(ctx, M[1].data(), M[1].rows() * M[1].cols()) {}
+};
+ABY3Engine::Pinned *ABY3Engine::find_pinned(const MatPair &M) const {
+    for (Pinned *p : pinned)
+        if (p->key == &M) return p;
+    return nullptr;
+}
+void ABY3Engine::pin(const MatPair &M) {
+    assert(M[0].rows() == M[1].rows() && M[0].cols() == M[1].cols());
+    unpin(M);
+    pinned.push_back(new Pinned(gpu, M));
+}
+void ABY3Engine::unpin(const MatPair &M) {
+    for (size_t i = 0; i < pinned.size(); i++)
+        if (pinned[i]->key == &M) {
+            delete pinned[i];
+            pinned.erase(pinned.begin() + i);
+            return;
+        }
+}
+
 ABY3Engine::~ABY3Engine() {
+    for (Pinned *p : pinned) delete p;
+    pinned.clear();
     if (group)
         mpcx_group_shutdown(group);
     else
@@ -329,8 +359,21 @@ void ABY3Engine::matrix_mul(const array<MatrixXl, 2> &Xj, const array<MatrixXl, 
     } else {
         Dev<int64_t> z(gpu, rows * cols);
         std::unique_ptr<mpcgpu::Span> up(new mpcgpu::Span("matrix_mul: upload"));
-        Dev<int64_t> x0(gpu, Xj[0].data(), rows * lens), x1(gpu, Xj[1].data(), rows * lens);
-        Dev<int64_t> y0(gpu, Yj[0].data(), lens * cols), y1(gpu, Yj[1].data(), lens * cols);
+        // operands the caller pinned are on the device already
+        const Pinned *px = find_pinned(Xj), *py = find_pinned(Yj);
+        assert(!px || (px->rows == rows && px->cols == lens));
+        assert(!py || (py->rows == lens && py->cols == cols));
+        std::unique_ptr<Dev<int64_t>> ux0, ux1, uy0, uy1;
+        if (!px) {
+            ux0.reset(new Dev<int64_t>(gpu, Xj[0].data(), rows * lens));
+            ux1.reset(new Dev<int64_t>(gpu, Xj[1].data(), rows * lens));
+        }
+        if (!py) {
+            uy0.reset(new Dev<int64_t>(gpu, Yj[0].data(), lens * cols));
+            uy1.reset(new Dev<int64_t>(gpu, Yj[1].data(), lens * cols));
+        }
+        const int64_t *x0 = px ? px->s0.p : ux0->p, *x1 = px ? px->s1.p : ux1->p;
+        const int64_t *y0 = py ? py->s0.p : uy0->p, *y1 = py ? py->s1.p : uy1->p;
         up.reset();
         // Eigen stores column-major (layout 1); the result comes back row-major = the wire order
         {
@@ -571,5 +614,128 @@ void ABY3Engine::bit_inject(const array<VecI64, 2> &Aj, const array<vecbool, 2> 
     reveal_bools(Bj, bd);
     reveal(Cj, cd);
     for (size_t i = 0; i < (size_t)cd.size(); i++) assert(cd[i] == (bd[i] ? ad[i] : 0));
+#endif
+}
+
+// ---- ReLU as one protocol.  Written over element ranges (mpcgpu::run): the whole vector on the engine's one GPU, or
+// every member of the group its own range.  The rounds, the bytes of every message and the generator words are those
+// of add_prepare (:295-326), msb (:361-467) and bit_inject (:510-1038) called one after the other; the last segment is
+// bit_inject's fused with the subtraction R = X - C.
+void ABY3Engine::relu(const VecPair &Xj, VecPair &Rj) {
+    using mpcgpu::Bufs;
+    using mpcgpu::fresh;
+    const Peers pe(party_id);
+    const size_t n = Xj[0].size(), G = mpcgpu::members(*this), id = party_id;
+    assert((size_t)Xj[1].size() == n);
+    Bufs<int64_t> x0(G), x1(G), c0(G), c1(G), p0(G), p1(G), g0(G), g1(G);
+    Bufs<uint64_t> state(G);
+    Bufs<int8_t> msg_in(G), msg_out(G), z0(G), z1(G);
+    string &out = message_send[pe.prev];
+    // add_prepare, round 1: C0 = X0 & X1
+    message_send[pe.next].clear();
+    out.resize(n * W8);
+    mpcgpu::run(*this, n, [&](mpcx_ctx *ctx, int m, uint64_t i0, uint64_t cnt) {
+        fresh(x0[m], ctx, cnt).up(Xj[0].data() + i0, cnt);
+        fresh(x1[m], ctx, cnt).up(Xj[1].data() + i0, cnt);
+        GPU_OK(ctx, mpcx_aby3_add_prepare_step1(ctx, *x0[m], *x1[m], cnt, fresh(c0[m], ctx, cnt)));
+        mpcgpu::put(*c0[m], out, 0, i0, cnt);
+    });
+    messenger->send_and_recv(message_send, message_recv);
+    MSG_CHECK(message_recv[pe.next].size() == n * W8);
+    // round 2: G0
+    mpcgpu::run(*this, n, [&](mpcx_ctx *ctx, int m, uint64_t i0, uint64_t cnt) {
+        mpcgpu::get(fresh(c1[m], ctx, cnt), message_recv[pe.next], 0, i0, cnt);
+        fresh(p0[m], ctx, cnt);
+        fresh(p1[m], ctx, cnt);
+        fresh(g0[m], ctx, cnt);
+        GPU_OK(ctx, mpcx_aby3_add_prepare_step2(ctx, *x0[m], *x1[m], *c0[m], *c1[m], cnt, *p0[m], *p1[m], *g0[m]));
+        mpcgpu::put(*g0[m], out, 0, i0, cnt);
+        c0[m].reset();
+        c1[m].reset();
+    });
+    messenger->send_and_recv(message_send, message_recv);
+    MSG_CHECK(message_recv[pe.next].size() == n * W8);
+    // msb: the first message from G, P where they lie; then one call per received message
+    out.resize(64 * n);
+    mpcgpu::run(*this, n, [&](mpcx_ctx *ctx, int m, uint64_t i0, uint64_t cnt) {
+        mpcgpu::get(fresh(g1[m], ctx, cnt), message_recv[pe.next], 0, i0, cnt);
+        fresh(state[m], ctx, 6 * cnt);
+        fresh(msg_in[m], ctx, 64 * cnt);
+        fresh(msg_out[m], ctx, 64 * cnt);
+        fresh(z0[m], ctx, cnt);
+        fresh(z1[m], ctx, cnt);
+        GPU_OK(ctx, mpcx_aby3_msb_begin(ctx, *g0[m], *g1[m], *p0[m], *p1[m], cnt, *state[m]));
+        GPU_OK(ctx, mpcx_aby3_msb_round_pre(ctx, *state[m], cnt, 32, *msg_out[m]));
+        if (cnt) msg_out[m]->down(&out[64 * i0], 64 * cnt);
+    });
+    for (size_t temp = 32; temp != 0; temp /= 2) {
+        const size_t per = 2 * temp; // message bytes per element of this round
+        out.resize(per * n);
+        messenger->send_and_recv(message_send, message_recv);
+        const string &in = message_recv[pe.next];
+        MSG_CHECK(in.size() == per * n);
+        if (temp != 1) out.resize(per / 2 * n); // the next message is written in place, slice by slice
+        mpcgpu::run(*this, n, [&](mpcx_ctx *ctx, int m, uint64_t i0, uint64_t cnt) {
+            if (!cnt) return;
+            GPU_OK(ctx, mpcx_h2d(ctx, msg_in[m]->p, in.data() + per * i0, per * cnt));
+            if (temp != 1) {
+                GPU_OK(ctx, mpcx_aby3_msb_round_mid(ctx, *state[m], cnt, temp, *msg_in[m], *msg_out[m]));
+                msg_out[m]->down(&out[per / 2 * i0], per / 2 * cnt);
+            } else {
+                GPU_OK(ctx, mpcx_aby3_msb_last(ctx, *state[m], cnt, *msg_in[m], *z0[m], *z1[m]));
+            }
+        });
+    }
+    // bit_inject on (X, sign bits), its last segment fused with the subtraction
+    const size_t a = (id + 1) % 3, b = (id + 2) % 3;
+    static const size_t send_sections[3][3] = {{0, 2, 3}, {2, 0, 3}, {1, 1, 0}}; // [from][to], in vectors of n words
+    PRgenerator &sA = prgs[id == 0 ? 1 : 0], &sB = prgs[id == 2 ? 1 : 2]; // P0: s01, s20; P1: s01, s12; P2: s20, s12
+    const uint64_t popA = sA.pops, popB = sB.pops;
+    Bufs<int64_t> toA(G), toB(G), fromA(G), fromB(G), r0(G), r1(G);
+    for (auto &m : message_send) m.clear();
+    message_send[a].resize(send_sections[id][a] * n * W8);
+    message_send[b].resize(send_sections[id][b] * n * W8);
+    mpcgpu::run(*this, n, [&](mpcx_ctx *ctx, int m, uint64_t i0, uint64_t cnt) {
+        p0[m].reset(), p1[m].reset(), g0[m].reset(), g1[m].reset(), state[m].reset(), msg_in[m].reset(), msg_out[m].reset();
+        fresh(toA[m], ctx, send_sections[id][a] * cnt);
+        fresh(toB[m], ctx, send_sections[id][b] * cnt);
+        if (id == 0)
+            GPU_OK(ctx, mpcx_aby3_bit_inject_p0_pre(ctx, *x0[m], *z0[m], *z1[m], n, i0, cnt, sA.init_seed, popA, sB.init_seed, popB, *toA[m], *toB[m]));
+        else if (id == 1)
+            GPU_OK(ctx, mpcx_aby3_bit_inject_p1_pre(ctx, *x0[m], *x1[m], *z0[m], *z1[m], n, i0, cnt, sA.init_seed, popA, sB.init_seed, popB, *toB[m], *toA[m]));
+        else
+            GPU_OK(ctx, mpcx_aby3_bit_inject_p2_pre(ctx, *z0[m], *z1[m], n, i0, cnt, sA.init_seed, popA, sB.init_seed, popB, *toA[m], *toB[m]));
+        sections_down(*toA[m], message_send[a], send_sections[id][a], n, i0, cnt);
+        sections_down(*toB[m], message_send[b], send_sections[id][b], n, i0, cnt);
+    });
+    sA.advance(gpu, (id == 2 ? 3 : 6) * n);
+    sB.advance(gpu, 3 * n);
+    messenger->send_and_recv(message_send, message_recv);
+    MSG_CHECK(message_recv[a].size() == send_sections[a][id] * n * W8 && message_recv[b].size() == send_sections[b][id] * n * W8);
+    Rj[0].resize(n);
+    Rj[1].resize(n);
+    mpcgpu::run(*this, n, [&](mpcx_ctx *ctx, int m, uint64_t i0, uint64_t cnt) {
+        fresh(fromA[m], ctx, send_sections[a][id] * cnt);
+        fresh(fromB[m], ctx, send_sections[b][id] * cnt);
+        fresh(r0[m], ctx, cnt);
+        fresh(r1[m], ctx, cnt);
+        sections_up(ctx, *fromA[m], message_recv[a], send_sections[a][id], n, i0, cnt);
+        sections_up(ctx, *fromB[m], message_recv[b], send_sections[b][id], n, i0, cnt);
+        if (id == 0)
+            GPU_OK(ctx, mpcx_aby3_bit_inject_p0_post_sub(ctx, *z0[m], n, i0, cnt, sA.init_seed, popA, sB.init_seed, popB, *fromA[m], *fromB[m], *x0[m], *x1[m], *r0[m], *r1[m]));
+        else if (id == 1)
+            GPU_OK(ctx, mpcx_aby3_bit_inject_p1_post_sub(ctx, *z1[m], n, i0, cnt, sA.init_seed, popA, sB.init_seed, popB, *fromB[m], *fromA[m], *x0[m], *x1[m], *r0[m], *r1[m]));
+        else
+            GPU_OK(ctx, mpcx_aby3_bit_inject_p2_post_sub(ctx, *z0[m], *z1[m], n, i0, cnt, sA.init_seed, popA, sB.init_seed, popB, *fromA[m], *fromB[m], *x0[m], *x1[m], *r0[m], *r1[m]));
+        if (cnt) {
+            r0[m]->down(Rj[0].data() + i0, cnt);
+            r1[m]->down(Rj[1].data() + i0, cnt);
+        }
+    });
+#if defined MYDEBUG // the opened result is max(x, 0)
+    VecI64 xd, rd;
+    reveal(Xj, xd);
+    reveal(Rj, rd);
+    for (size_t i = 0; i < (size_t)rd.size(); i++) assert(rd[i] == (xd[i] < 0 ? 0 : xd[i]));
 #endif
 }

@@ -77,4 +77,21 @@ class ABY3Engine {
     // ---- fixed-point rescale and arithmetic-times-bit (:469-1038)
     void trunc(const VecPair &X, VecPair &Y, size_t number);
     void bit_inject(const VecPair &A, const BitPair &B, VecPair &C);
+
+    // ---- additions (no counterpart in the reference class; everything above is unchanged)
+    // R = ReLU(X) = X - bit_inject(X, msb(add_prepare(X))), the composition the reference benchmarks
+    // (benchmark/benchmark1.cpp:71-73) followed by the subtraction of the two share vectors, as ONE protocol: the same
+    // nine rounds, messages and generator words as the three calls, but G, P, the carry tree and the sign bits stay
+    // on the device between the rounds (only messages cross to the host).  Bit-identical to the composition.
+    void relu(const VecPair &X, VecPair &R);
+    // Keeps a device copy of a share pair (e.g. a weight matrix that many products use) until unpin: matrix_mul finds
+    // an operand by the address of its pair and skips the upload.  Explicit on purpose: the caller promises not to
+    // change or destroy a pinned pair.  The destructor releases what is still pinned.
+    void pin(const MatPair &M);
+    void unpin(const MatPair &M);
+
+  private:
+    struct Pinned;
+    std::vector<Pinned *> pinned;
+    Pinned *find_pinned(const MatPair &M) const;
 };

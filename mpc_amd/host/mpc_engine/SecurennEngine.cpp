@@ -37,7 +37,34 @@ SecurennEngine::SecurennEngine(VirtuleMessenger *_messenger, size_t _party_id)
     gpu = group ? mpcx_group_ctx(group, 0) : mpcgpu::open_context();
 }
 
+// a share matrix kept on the engine's first GPU, column-major as Eigen stores it
+struct SecurennEngine::Pinned {
+    const MatrixXl *key;
+    size_t rows, cols;
+    Dev<int64_t> d;
+    Pinned(mpcx_ctx *ctx, const MatrixXl &M) : key(&M), rows(M.rows()), cols(M.cols()), d(ctx, M.data(), M.rows() * M.cols()) {}
+};
+SecurennEngine::Pinned *SecurennEngine::find_pinned(const MatrixXl &M) const {
+    for (Pinned *p : pinned)
+        if (p->key == &M) return p;
+    return nullptr;
+}
+void SecurennEngine::pin(const MatrixXl &M) {
+    unpin(M);
+    if (party_id != 2) pinned.push_back(new Pinned(gpu, M)); // party 2 holds no share
+}
+void SecurennEngine::unpin(const MatrixXl &M) {
+    for (size_t i = 0; i < pinned.size(); i++)
+        if (pinned[i]->key == &M) {
+            delete pinned[i];
+            pinned.erase(pinned.begin() + i);
+            return;
+        }
+}
+
 SecurennEngine::~SecurennEngine() {
+    for (Pinned *p : pinned) delete p;
+    pinned.clear();
     if (group)
         mpcx_group_shutdown(group);
     else
@@ -89,8 +116,14 @@ void SecurennEngine::matrix_mul(const MatrixXl &Xj, const MatrixXl &Yj, MatrixXl
     string triple_msg; // round 2 overwrites the slot; a group reads the triple from the host once more
     if (group) triple_msg.swap(message_recv[2]);
     {
-        Dev<int64_t> x(gpu, Xj.data(), na), y(gpu, Yj.data(), nb);
-        GPU_OK(gpu, mpcx_snn_beaver_party_open_matmul(gpu, x, y, 1, triple, rows, lens, cols, ef));
+        const Pinned *px = find_pinned(Xj), *py = find_pinned(Yj); // operands the caller pinned are on the device already
+        assert(!px || (px->rows == rows && px->cols == lens));
+        assert(!py || (py->rows == lens && py->cols == cols));
+        std::unique_ptr<Dev<int64_t>> ux, uy;
+        if (!px) ux.reset(new Dev<int64_t>(gpu, Xj.data(), na));
+        if (!py) uy.reset(new Dev<int64_t>(gpu, Yj.data(), nb));
+        GPU_OK(gpu, mpcx_snn_beaver_party_open_matmul(gpu, px ? px->d.p : ux->p, py ? py->d.p : uy->p, 1, triple, rows, lens,
+                                                      cols, ef));
     }
     ef.to_string(message_send[peer]);
     message_send[2].clear();
@@ -600,4 +633,36 @@ void SecurennEngine::msb(const vector<int64_t> &Aj, vector<int64_t> &Bj) {
     share_convert_dev(*this, &twoA, n, &y);
     msb_L1_dev(*this, &y, n, &b);
     gather(*this, b, n, Bj.data());
+}
+
+// ---- ReLU(a) = a - a * [a < 0] as one protocol: msb (ten rounds), vector_mul (two rounds), subtraction
+void SecurennEngine::relu(const vector<int64_t> &Aj, vector<int64_t> &Rj) {
+#if defined MYDEBUG // the opened result is max(a, 0)
+    mpcgpu::AtExit check([&] {
+        vector<int64_t> ad, rd;
+        reveal(Aj, ad);
+        reveal(Rj, rd);
+        for (size_t i = 0; i < ad.size(); i++) assert(rd[i] == (ad[i] < 0 ? 0 : ad[i]));
+    });
+#endif
+    const size_t n = Aj.size(), G = members(*this);
+    Rj.assign(n, 0);
+    if (party_id == 2) {
+        share_convert_dev(*this, nullptr, n, nullptr);
+        msb_L1_dev(*this, nullptr, n, nullptr);
+        vecmul_dealer(*this, n);
+        return;
+    }
+    Bufs<int64_t> a(G), twoA(G), y(G), b(G), z(G), r(G);
+    scatter(*this, Aj.data(), n, 1, a);
+    run(*this, n, [&](mpcx_ctx *ctx, int m, uint64_t, uint64_t cnt) {
+        GPU_OK(ctx, mpcx_ring_shl1(ctx, a[m]->p, fresh(twoA[m], ctx, cnt), cnt));
+    });
+    share_convert_dev(*this, &twoA, n, &y);
+    msb_L1_dev(*this, &y, n, &b);
+    vecmul_party_dev(*this, a, b, n, z);
+    run(*this, n, [&](mpcx_ctx *ctx, int m, uint64_t, uint64_t cnt) {
+        GPU_OK(ctx, mpcx_ring_sub(ctx, a[m]->p, z[m]->p, fresh(r[m], ctx, cnt), cnt));
+    });
+    gather(*this, r, n, Rj.data());
 }

@@ -67,4 +67,19 @@ class SecurennEngine {
     void shareConvert(const Words &A, Words &Y);
     void msb_L_1(const Words &A, Words &B);
     void msb(const Words &A, Words &B);
+
+    // ---- additions (no counterpart in the reference class; everything above is unchanged)
+    // R = ReLU(A) = A - vector_mul(A, msb(A)), the composition the reference benchmarks (benchmark/benchmark1.cpp:135-136)
+    // followed by the subtraction, as ONE protocol: the same twelve rounds and messages, with the sign shares, the
+    // product and the input kept on the device in between.  Bit-identical to the three steps done one after the other.
+    void relu(const Words &A, Words &R);
+    // Keeps a device copy of a share matrix (e.g. a weight matrix) until unpin: matrix_mul finds an operand by its
+    // address and skips the upload.  The caller promises not to change or destroy a pinned matrix.
+    void pin(const MatrixXl &M);
+    void unpin(const MatrixXl &M);
+
+  private:
+    struct Pinned;
+    std::vector<Pinned *> pinned;
+    Pinned *find_pinned(const MatrixXl &M) const;
 };

@@ -338,6 +338,114 @@ static void my_party(InProcHub *hub, size_t p) {
     }
 }
 
+// relu as one protocol against the calls it is made of followed by the subtraction, each on FRESH engines: the same
+// share words, the same generator positions afterwards; and matrix_mul with a pinned operand against the plain call
+static void aby3_additions_party(InProcHub *hub, size_t p) {
+    InProcMessenger msgr(hub, p);
+    PRgenerator g(21, 0);
+    const size_t n = 3001; // not a multiple of the 64-element range granule
+    VecI64 X(n), Rr;
+    for (size_t i = 0; i < n; i++) X[i] = g.pop_int64();
+    X[0] = 0, X[1] = -1, X[2] = 1, X[3] = INT64_MIN, X[4] = INT64_MAX;
+    array<VecI64, 2> R1, R2;
+    uint64_t pops1[3], pops2[3];
+    {
+        ABY3Engine e(&msgr, p);
+        array<VecI64, 2> Xj, Gj, Pj, Cj;
+        array<vecbool, 2> Zj;
+        e.share(X, Xj);
+        e.add_prepare(Xj, Gj, Pj);
+        e.msb(Gj, Pj, Zj);
+        e.bit_inject(Xj, Zj, Cj);
+        for (int k = 0; k < 2; k++) {
+            R1[k].resize(n);
+            for (size_t i = 0; i < n; i++) R1[k][i] = (int64_t)((uint64_t)Xj[k][i] - (uint64_t)Cj[k][i]);
+        }
+        for (int k = 0; k < 3; k++) pops1[k] = e.prgs[k].pops;
+    }
+    {
+        ABY3Engine e(&msgr, p);
+        array<VecI64, 2> Xj;
+        e.share(X, Xj);
+        e.relu(Xj, R2);
+        for (int k = 0; k < 3; k++) pops2[k] = e.prgs[k].pops;
+        e.reveal(R2, Rr);
+    }
+    CHECK(R1[0] == R2[0] && R1[1] == R2[1]);
+    for (int k = 0; k < 3; k++) CHECK(pops1[k] == pops2[k]);
+    for (size_t i = 0; i < n; i++) CHECK(Rr[i] == (X[i] < 0 ? 0 : X[i]));
+    printf("KAT aby3_relu_fused_3001_R0 %zu %016lX\n", p, (unsigned long)fnv(R2[0].data(), n));
+    {
+        ABY3Engine e(&msgr, p);
+        PRgenerator h(32, 0);
+        MatrixXl A(37, 50), B(50, 29);
+        for (size_t i = 0; i < 37; i++)
+            for (size_t j = 0; j < 50; j++) A(i, j) = h.pop_int64();
+        for (size_t i = 0; i < 50; i++)
+            for (size_t j = 0; j < 29; j++) B(i, j) = h.pop_int64();
+        array<MatrixXl, 2> Aj, Bj, Z1, Z2, Z3;
+        e.share_matrix(A, Aj);
+        e.share_matrix(B, Bj);
+        e.pin(Bj);
+        e.matrix_mul(Aj, Bj, Z1); // B from its device copy
+        e.pin(Aj);
+        e.matrix_mul(Aj, Bj, Z2); // both
+        e.unpin(Aj);
+        e.unpin(Bj);
+        e.matrix_mul(Aj, Bj, Z3); // neither
+        MatrixXl P1, P2, P3;
+        e.reveal_matrix(Z1, P1);
+        e.reveal_matrix(Z2, P2);
+        e.reveal_matrix(Z3, P3);
+        CHECK(P1 == A * B && P2 == P1 && P3 == P1);
+    }
+}
+static void snn_additions_party(InProcHub *hub, size_t p) {
+    InProcMessenger msgr(hub, p);
+    PRgenerator g(23, 0);
+    const size_t n = 2001;
+    vector<int64_t> A(n), R1(n), R2, Rr;
+    for (auto &a : A) a = g.pop_int64() / 2;
+    A[0] = 0, A[1] = -1, A[2] = 1;
+    {
+        SecurennEngine e(&msgr, p);
+        vector<int64_t> Aj, Bj, Mj;
+        e.share(A, Aj);
+        e.msb(Aj, Bj);
+        e.vector_mul(Aj, Bj, Mj);
+        for (size_t i = 0; i < n; i++) R1[i] = p == 2 ? 0 : (int64_t)((uint64_t)Aj[i] - (uint64_t)Mj[i]);
+    }
+    {
+        SecurennEngine e(&msgr, p);
+        vector<int64_t> Aj;
+        e.share(A, Aj);
+        e.relu(Aj, R2);
+        e.reveal(R2, Rr);
+    }
+    CHECK(R1 == R2);
+    if (p != 2)
+        for (size_t i = 0; i < n; i++) CHECK(Rr[i] == (A[i] < 0 ? 0 : A[i]));
+    if (p != 2) printf("KAT snn_relu_fused_2001_R %zu %016lX\n", p, (unsigned long)fnv(R2.data(), n));
+    {
+        SecurennEngine e(&msgr, p);
+        PRgenerator h(34 + p, 0);
+        MatrixXl Mx(13, 21), My(21, 8), Z1, Z2, P1, P2, Px, Py;
+        for (size_t i = 0; i < 13; i++)
+            for (size_t j = 0; j < 21; j++) Mx(i, j) = h.pop_int64();
+        for (size_t i = 0; i < 21; i++)
+            for (size_t j = 0; j < 8; j++) My(i, j) = h.pop_int64();
+        e.pin(My);
+        e.matrix_mul(Mx, My, Z1);
+        e.unpin(My);
+        e.matrix_mul(Mx, My, Z2);
+        e.reveal_matrix(Mx, Px);
+        e.reveal_matrix(My, Py);
+        e.reveal_matrix(Z1, P1);
+        e.reveal_matrix(Z2, P2);
+        CHECK(P1 == Px * Py && P2 == P1);
+    }
+}
+
 template <class F> static void run3(F party) {
     InProcHub hub;
     std::thread t0(party, &hub, 0), t1(party, &hub, 1), t2(party, &hub, 2);
@@ -375,6 +483,8 @@ int main() {
     run3(aby3_party);
     run3(snn_party);
     run3(my_party);
+    run3(aby3_additions_party);
+    run3(snn_additions_party);
     if (failures.load()) {
         printf("host_selftest: %d check(s) FAILED\n", failures.load());
         return 1;

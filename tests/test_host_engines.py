@@ -77,8 +77,10 @@ def test_host_headers_keep_the_reference_surface():
 
 
 @pytest.mark.gpu
-def test_host_engines_selftest_and_known_answers():
-    """Three party threads, in-process messenger, every engine method; share checksums equal the oracle's."""
+def test_host_engines_selftest_and_known_answers(orc):
+    """Three party threads, in-process messenger, every engine method; share checksums equal the oracle's.  The
+    engines' relu (one protocol, device-resident between its rounds) is compared inside the program with the calls it
+    is made of, word for word and generator position for generator position, and here with the oracle's chain."""
     exe = os.path.join(HOST, "host_selftest")
     assert os.path.exists(exe), "mpc_amd/host/host_selftest missing: run __graft_entry__.build()"
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
@@ -92,6 +94,27 @@ def test_host_engines_selftest_and_known_answers():
     assert [kat[("aby3_matmul_64_Z0", j)] for j in range(3)] == g["Z_share0"]
     assert {kat[("aby3_matmul_64_Zplain", j)] for j in range(3)} == {g["Z_plain"]}
     assert [kat[("snn_msb_1000_B", j)] for j in range(2)] == GOLD["snn_msb_1000"]["B_share"]
+    # ABY3Engine::relu on 3001 values of PRgenerator(21,0) (the first five replaced by corner values) against the
+    # oracle's share -> add_prepare -> msb -> bit_inject -> subtract
+    import protocols as pr
+    from oracle_lib import fnv1a64, prg_pops
+    X = prg_pops(21, 0, 3001)
+    X[:5] = [0, -1, 1, -2 ** 63, 2 ** 63 - 1]
+    w = pr.World(orc)
+    Xs = pr.aby3_share(w, X, X.size)
+    Gs, Ps = pr.aby3_add_prepare(w, Xs)
+    C = pr.aby3_bit_inject(w, Xs, pr.aby3_msb(w, Gs, Ps))
+    for j in range(3):
+        assert kat[("aby3_relu_fused_3001_R0", j)] == "%016X" % fnv1a64(orc.ring_sub(Xs[j][0], C[j][0]))
+    # SecurennEngine::relu on 2001 values pop / 2 of PRgenerator(23,0) (the first three replaced)
+    A = prg_pops(23, 0, 2001)
+    A = (A + (A < 0)) >> 1  # pop / 2 in C++ truncates toward zero
+    A[:3] = [0, -1, 1]
+    w = pr.World(orc)
+    As = pr.snn_share(w, A, A.size)[:2]
+    M = pr.snn_vecmul(w, As, pr.snn_msb(w, As))
+    for j in range(2):
+        assert kat[("snn_relu_fused_2001_R", j)] == "%016X" % fnv1a64(orc.ring_sub(As[j], M[j]))
 
 
 @pytest.mark.gpu
