@@ -76,6 +76,22 @@ def test_host_headers_keep_the_reference_surface():
             assert member in hdr
 
 
+def test_host_surface_compiles_to_the_reference_signatures():
+    """mpc_amd/host/test/surface_check.cpp states, as static_asserts on pointer-to-member types, every public method,
+    data member, alias, constant and codec of the reference's headers with its exact signature, and the idioms the
+    reference's drivers use on an engine (prgs[k].pop_int64(), int_buff, party_id).  Syntax-only compile, nothing is
+    linked or run; the negative control (one deliberately wrong signature) must fail."""
+    import shutil
+    if not shutil.which("g++"):
+        pytest.skip("no host compiler")
+    src = os.path.join(HOST, "test", "surface_check.cpp")
+    cmd = ["g++", "-std=c++17", "-fsyntax-only", "-Wno-sign-compare", src]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run(cmd + ["-DSURFACE_NEGATIVE_CONTROL"], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "static assertion failed" in r.stderr
+
+
 @pytest.mark.gpu
 def test_host_engines_selftest_and_known_answers(orc):
     """Three party threads, in-process messenger, every engine method; share checksums equal the oracle's.  The
