@@ -907,7 +907,8 @@ def config5_multi(ctx, torch, dev, dist, rank, world, tables, gather_to, host_ga
     job.verify()
     ops_alg = 3 * 36 * 2 * full * full * (2 * full)  # three parties, one product of depth 2 l each
     out["matmul"] = {"workload": f"ABY3 {full}x{full} . {full}x{full} share matmul + reconstruct, 3 parties per step, "
-                                 f"{full // world} rows per rank, Y replicated, 4 accumulation chunks, gather to "
+                                 f"{full // world} rows per rank, Y replicated, {max(1, 2 * full // 8192)} accumulation chunk(s) "
+                                 "per product, gather to "
                                  + ("rank 0" if gather_to == "root" else "every rank"),
                      "ms_per_step": round(dt / steps * 1e3, 2), "steps": steps,
                      "ring_Gops": round(3 * 3 * 2 * full ** 3 / (dt / steps) / 1e9, 1),

@@ -60,6 +60,27 @@ def _worker(rank, world, port, out_dir):
     dist.all_gather(dparts, torch.from_numpy(d.view(np.int64)))
     dall = torch.cat(dparts).numpy().view(np.uint16)
     ok = ok and np.array_equal(dall, orc.snn_pc_party(0, s0, beta, rr, n, 0, KEY01))
+
+    # strong scaling, the shape of the 16384 x 16384 configuration at a reduced row count: c = 16384 columns, the row
+    # block's mask words start row0 * c words into both pop streams (ABY3Engine.cpp:190-197: row-major order), and one of
+    # the two streams is read beyond 2^32 words
+    r5, l5, c5 = 8, 4, 16384
+    A0, A1, B0, B1 = [rng.integers(-2 ** 63, 2 ** 63, k, dtype=np.int64) for k in (r5 * l5, r5 * l5, l5 * c5, l5 * c5)]
+    far, near = (1 << 32) + 12345, aby3_matmul_pop_plan(r5, l5, c5)["matmul"]
+    row0, rows = matmul_row_block(r5, world, rank)
+    blk = orc.aby3_matmul_local(A0[row0 * l5:(row0 + rows) * l5], A1[row0 * l5:(row0 + rows) * l5], B0, B1, rows, l5, c5, 0,
+                                KEY01, far + row0 * c5, KEY20, near + row0 * c5)
+    parts = [torch.empty(rows * c5, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(parts, torch.from_numpy(blk))
+    ok = ok and np.array_equal(torch.cat(parts).numpy(), orc.aby3_matmul_local(A0, A1, B0, B1, r5, l5, c5, 0, KEY01, far, KEY20, near))
+    # element ranges whose pop offsets straddle 2^32 words: share (one word per element and stream)
+    ns, edge = 400, (1 << 32) - 150
+    xs = rng.integers(-2 ** 63, 2 ** 63, ns, dtype=np.int64)
+    i0, m = split_range(ns, world, rank)
+    sh = orc.aby3_share_local(xs[i0:i0 + m], m, KEY01, edge + i0, KEY20, 77 + i0)
+    sparts = [torch.empty(m, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(sparts, torch.from_numpy(sh))
+    ok = ok and np.array_equal(torch.cat(sparts).numpy(), orc.aby3_share_local(xs, ns, KEY01, edge, KEY20, 77))
     open(os.path.join(out_dir, f"rank{rank}.ok"), "w").write("1" if ok else "0")
     dist.barrier()
     dist.destroy_process_group()
