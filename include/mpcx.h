@@ -110,12 +110,15 @@ const char *mpcx_ring_gemm_kernel_name(uint64_t r, uint64_t l, uint64_t c);
  * loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments and results; the limb
  * planes live in a file-scope device array of mpcx_ring_gemm_noalloc_limit() = 16 MiB per GPU (held until the process
  * ends) instead of the context workspace, and the call makes no hipMalloc / hipFree and creates no events.  Always
- * the digit-pair kernels.  Shapes whose planes (8 * (ceil128(r) + ceil128(c)) * min(ceil64(l), 8192) bytes) exceed the
- * limit are rejected with an error, e.g. 1024 x 1024 x 1024 and 128 x 8192 x 128 fit.  Every call on a GPU shares that
- * GPU's array: calls that overlap in time on one GPU (two contexts, two streams) race. */
+ * the digit-pair kernels.  A shape needs mpcx_ring_gemm_noalloc_bytes(r, l, c) bytes of planes: 8 * (ceil128(r) +
+ * ceil128(c)) * kc, where kc = ceil64(l) halved (and rounded up to 64 again) until it is at most 8192, the length of
+ * one accumulation chunk; shapes that need more than the limit are rejected with an error, e.g. 1024 x 1024 x 1024 and
+ * 128 x 8192 x 128 fit.  Every call on a GPU shares that GPU's array: calls that overlap in time on one GPU (two
+ * contexts, two streams) race. */
 int mpcx_ring_gemm_u64_noalloc(mpcx_ctx *ctx, const int64_t *A, const int64_t *B, int64_t *C, uint64_t r, uint64_t l,
                                uint64_t c, int layoutA, int layoutB, int layoutC, int accumulate);
 uint64_t mpcx_ring_gemm_noalloc_limit(void);
+uint64_t mpcx_ring_gemm_noalloc_bytes(uint64_t r, uint64_t l, uint64_t c);
 int mpcx_ring_add(mpcx_ctx *ctx, const int64_t *a, const int64_t *b, int64_t *out, uint64_t n);
 int mpcx_ring_sub(mpcx_ctx *ctx, const int64_t *a, const int64_t *b, int64_t *out, uint64_t n);
 int mpcx_ring_sar(mpcx_ctx *ctx, const int64_t *a, int64_t *out, uint64_t n, int k); /* benchmark/benchmark1.cpp:106-112 */

@@ -199,22 +199,20 @@ int mpcx_group_aby3_matmul_local(mpcx_group *g, const int64_t *X0, const int64_t
             G_TRY(mpcx_h2d(ctx, py0, Y0, 8 * l * c));
             G_TRY(mpcx_h2d(ctx, py1, Y1, 8 * l * c));
         } else {
-            // column-major operands (how Eigen stores MatrixXl): rows of X are strided on the host, so the whole
-            // matrix goes up and is turned on the device; the member keeps its rows
-            const u64 big = r * l > l * c ? r * l : l * c;
+            // column-major operands (how Eigen stores MatrixXl): the member's rows of X are a strided slab on the host --
+            // `rows` consecutive words in each of the l columns -- which one 2-D copy brings up as a rows x l
+            // column-major block; it is turned on the device.  Only the member's share of X crosses the link.
+            const u64 big = rows * l > l * c ? rows * l : l * c;
             G_TRY(mpcx_malloc(ctx, 8 * big, &tmp));
-            void *full = nullptr;
-            G_TRY(mpcx_malloc(ctx, 8 * r * l, &full));
             for (int s = 0; s < 2; s++) {
-                int rc = mpcx_h2d(ctx, tmp, s ? X1 : X0, 8 * r * l);
-                if (!rc) rc = mpcx_relayout(ctx, (const i64 *)tmp, (i64 *)full, r, l, 1, 0);
-                if (!rc) rc = mpcx_d2d(ctx, s ? px1 : px0, (const i64 *)full + row0 * l, 8 * rows * l);
-                if (rc) {
-                    (void)mpcx_free(ctx, full);
+                const i64 *src = (s ? X1 : X0) + row0;
+                if (hipMemcpy2DAsync(tmp, 8 * rows, src, 8 * r, 8 * rows, l, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+                    hipStreamSynchronize(ctx->stream) != hipSuccess) {
+                    mpcx_fail(ctx, "mpcx_group_aby3_matmul_local: the copy of a row block failed");
                     return release(1);
                 }
+                G_TRY(mpcx_relayout(ctx, (const i64 *)tmp, (i64 *)(s ? px1 : px0), rows, l, 1, 0));
             }
-            (void)mpcx_free(ctx, full);
             G_TRY(mpcx_h2d(ctx, tmp, Y0, 8 * l * c));
             G_TRY(mpcx_relayout(ctx, (const i64 *)tmp, (i64 *)py0, l, c, 1, 0));
             G_TRY(mpcx_h2d(ctx, tmp, Y1, 8 * l * c));

@@ -548,6 +548,7 @@ int mpcx_ring_gemm_u64_noalloc(mpcx_ctx *ctx, const int64_t *A, const int64_t *B
 }
 
 uint64_t mpcx_ring_gemm_noalloc_limit(void) { return STATIC_SCRATCH_BYTES; }
+uint64_t mpcx_ring_gemm_noalloc_bytes(uint64_t r, uint64_t l, uint64_t c) { return positional_ws_bytes(1, r, l, c); }
 
 int mpcx_ring_gemm_u64(mpcx_ctx *ctx, const int64_t *A, const int64_t *B, int64_t *C, uint64_t r, uint64_t l,
                        uint64_t c, int layoutA, int layoutB, int layoutC, int accumulate) {

@@ -31,8 +31,40 @@ def test_noalloc_ring_gemm_matches_the_allocating_entry_point(orc):
             out[name] = dC.to_host()
         assert np.array_equal(out["ring_gemm_u64_noalloc"], out["ring_gemm_u64"]), (r, l, c)
         assert np.array_equal(out["ring_gemm_u64"], orc.ring_gemm(A, B, r, l, c, la, lb, lc, C=C0 if acc else None)), (r, l, c)
+    # the size query: the halving of long contractions (l = 9000 -> chunks of 4544), and the limit's edge
+    nbytes = load_library().mpcx_ring_gemm_noalloc_bytes
+    nbytes.restype = ctypes.c_uint64
+    U = ctypes.c_uint64
+    assert nbytes(U(130), U(9000), U(66)) == 8 * (256 + 128) * 4544
+    assert nbytes(U(1024), U(1024), U(1024)) == 16 << 20 and nbytes(U(1025), U(1024), U(1024)) > 16 << 20
     one = ctx.to_device(np.zeros(1, np.int64))
     with pytest.raises(MpcxError, match="static scratch holds"):
         ctx.call("ring_gemm_u64_noalloc", one, one, one, 1025, 1024, 1024, 0, 0, 0, 0)
     with pytest.raises(MpcxError, match="bad shape"):
         ctx.call("ring_gemm_u64_noalloc", one, one, one, 0, 1, 1, 0, 0, 0, 0)
+
+
+def test_noalloc_ring_gemm_leaves_device_memory_untouched():
+    """On a context that has never run a product (its workspace is empty), a call of the no-alloc entry point at a size
+    that would make the allocating one grow the workspace by 16 MiB changes neither the free device memory nor the
+    context's workspace; the allocating entry point, called next as the control, does."""
+    import torch
+    from mpc_amd import Context
+    ctx = Context(0)
+    r = l = c = 1024
+    rng = np.random.default_rng(5)
+    dA = ctx.to_device(rng.integers(-2 ** 63, 2 ** 63, r * l, dtype=np.int64))
+    dB = ctx.to_device(rng.integers(-2 ** 63, 2 ** 63, l * c, dtype=np.int64))
+    dC, dD = ctx.empty(np.int64, r * c), ctx.empty(np.int64, r * c)
+    ctx.sync()
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info(0)[0]
+    for _ in range(3):
+        ctx.call("ring_gemm_u64_noalloc", dA, dB, dC, r, l, c, 0, 0, 0, 0)
+    ctx.sync()
+    assert torch.cuda.mem_get_info(0)[0] == free0, "the no-alloc entry point changed the free device memory"
+    ctx.call("ring_gemm_u64", dA, dB, dD, r, l, c, 0, 0, 0, 0)  # the control: this one takes a workspace
+    ctx.sync()
+    assert torch.cuda.mem_get_info(0)[0] <= free0 - (16 << 20)
+    assert np.array_equal(dC.to_host(), dD.to_host())
+    ctx.close()
