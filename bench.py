@@ -41,8 +41,8 @@ def pair_seed(a, b):
     return {frozenset((0, 1)): KEY01, frozenset((1, 2)): KEY12, frozenset((0, 2)): KEY20}[frozenset((a, b))]
 
 
-PMC_SUMMARY = "profiles/r2_pmc_summary.json"
-PMC_BITWISE = "profiles/r2_pmc_bitwise.json"
+PMC_SUMMARY = "profiles/r3_pmc_summary.json"
+PMC_BITWISE = "profiles/r3_pmc_bitwise.json"
 
 
 def measured_traffic(n, world, kernel="limb_gemm_kernel"):

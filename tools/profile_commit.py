@@ -35,7 +35,7 @@ for gname in ("limb_gemm_kernel", "rns_gemm_kernel", "rns_gemm_wide_kernel"):
         "hbm_read_bytes_per_launch": g["FETCH_SIZE"]["avg_value"] * 1024 * 2,
         "hbm_write_bytes_per_launch": g["WRITE_SIZE"]["avg_value"] * 1024,
         "note": "FETCH_SIZE / WRITE_SIZE are in KiB; FETCH_SIZE doubled (gfx950 tallies 128-B read requests at 64 B); "
-                "separate --pmc passes of `bench.py --steps 1 --warmup 0 --no-cpu --no-bitwise`",
+                "separate --pmc passes of `bench.py --steps 1 --warmup 0 --no-cpu --no-bitwise --no-extras`",
         "effective_clock_GHz": cyc / g["GRBM_GUI_ACTIVE"]["avg_duration_us"] / 1e3,
         "mfma_int8_ops": g["SQ_INSTS_VALU_MFMA_MOPS_I8"]["avg_value"] * 512,
         "mfma_pipe_utilisation_at_held_clock": g["SQ_INSTS_VALU_MFMA_MOPS_I8"]["avg_value"] * 512 / (256 * 4 * 2048) / cyc,
