@@ -55,7 +55,7 @@ int mpcx_d2h(mpcx_ctx *ctx, void *dst, const void *src, uint64_t bytes);
 int mpcx_d2d(mpcx_ctx *ctx, void *dst, const void *src, uint64_t bytes);
 /* mpcx_h2d / mpcx_d2h return when the copy is complete; host memory may be pageable (the std::string payloads of
  * VirtuleMessenger::send_and_recv, utils/VirtuleMessenger.hpp:14).  Transfers of 4 MiB and more are pipelined through
- * two pinned staging buffers of the context, DMA on one chunk while host threads (MPCX_COPY_THREADS; default: half the hardware threads, 4 to 16) copy
+ * two pinned staging buffers of the context, DMA on one chunk while host threads (MPCX_COPY_THREADS; default: three quarters of the hardware threads, 4 to 16) copy
  * the other.  mpcx_host_copy is that multi-threaded memcpy by itself, for messengers that move payloads between
  * host buffers (utils/SocketMessenger.cpp:142-164 does it through the kernel's socket buffers). */
 int mpcx_host_copy(void *dst, const void *src, uint64_t bytes);

@@ -23,9 +23,11 @@ struct CopyPool {
     std::deque<std::function<void()>> jobs;
     unsigned threads = 0;
     CopyPool() {
-        // default: half the hardware threads, between 4 and 16 (the callers copy and transpose alongside the pool)
+        // default: three quarters of the hardware threads, between 4 and 16.  The callers wait for the pool while it works,
+        // so their own threads do not compete with it; measured with three party threads on a 16-thread host
+        // (4096 x 4096 matrix_mul + trunc through the engines): 4 / 8 / 12 / 16 pool threads -> 347 / 178 / 137 / 136 ms.
         const char *e = getenv("MPCX_COPY_THREADS");
-        long n = e ? atol(e) : (long)(std::thread::hardware_concurrency() / 2);
+        long n = e ? atol(e) : (long)(std::thread::hardware_concurrency() * 3 / 4);
         if (!e) n = n < 4 ? 4 : n > 16 ? 16 : n;
         threads = (unsigned)(n < 0 ? 0 : n > 32 ? 32 : n);
         for (unsigned i = 0; i < threads; i++)

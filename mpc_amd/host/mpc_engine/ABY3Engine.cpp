@@ -541,8 +541,14 @@ void ABY3Engine::trunc(const array<VecI64, 2> &Xj, array<VecI64, 2> &Yj, size_t 
     assert(n == (size_t)Xj[1].size());
     // parties 1 and 2 draw from the stream they share: prgs[2] on party 1, prgs[1] on party 2
     const size_t k = party_id == 1 ? 2 : 1;
-    Dev<int64_t> x0(gpu, Xj[0].data(), n), x1(gpu, Xj[1].data(), n), y(gpu, n);
-    GPU_OK(gpu, mpcx_aby3_trunc_local(gpu, (int)party_id, x0, x1, n, (int)number, prgs[k].init_seed, prgs[k].pops, y));
+    // party 0 shifts its first share, party 1 the sum of its two, party 2 only draws from the stream (:480-503): each
+    // party uploads what its segment reads
+    Dev<int64_t> y(gpu, n);
+    std::unique_ptr<Dev<int64_t>> x0, x1;
+    if (party_id != 2) x0.reset(new Dev<int64_t>(gpu, Xj[0].data(), n));
+    if (party_id == 1) x1.reset(new Dev<int64_t>(gpu, Xj[1].data(), n));
+    GPU_OK(gpu, mpcx_aby3_trunc_local(gpu, (int)party_id, x0 ? x0->p : nullptr, x1 ? x1->p : nullptr, n, (int)number,
+                                      prgs[k].init_seed, prgs[k].pops, y));
     if (party_id != 0) prgs[k].advance(gpu, n);
     message_send[pe.next].clear();
     y.to_string(message_send[pe.prev]);
@@ -558,7 +564,11 @@ void ABY3Engine::bit_inject(const array<VecI64, 2> &Aj, const array<vecbool, 2> 
     if (group) return bit_inject_group(*this, Aj, Bj, Cj);
     const size_t w = n * sizeof(int64_t);
     for (auto &m : message_send) m.clear();
-    Dev<int64_t> a0(gpu, Aj[0].data(), n), a1(gpu, Aj[1].data(), n), c0(gpu, n), c1(gpu, n);
+    // the OT senders read a (party 0: its first share, party 1: both), party 2 only the bit shares: each party uploads
+    // what its segments read
+    Dev<int64_t> a0(gpu, party_id != 2 ? n : 0), a1(gpu, party_id == 1 ? n : 0), c0(gpu, n), c1(gpu, n);
+    if (party_id != 2) a0.up(Aj[0].data(), n);
+    if (party_id == 1) a1.up(Aj[1].data(), n);
     Dev<int8_t> b0(gpu, Bj[0].data(), n), b1(gpu, Bj[1].data(), n);
     if (party_id == 0) {
         PRgenerator &s01 = prgs[1], &s20 = prgs[2];
