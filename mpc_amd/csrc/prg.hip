@@ -5,10 +5,12 @@
 // 24-byte state every PRG_CK outputs; one GPU lane then replays one PRG_CK-word segment.  A
 // 256-thread workgroup therefore owns 256 consecutive segments; every 16 steps the lanes
 // park their words in LDS and the workgroup writes them out as whole 128-byte lines.
+#include <dlfcn.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
 #include <condition_variable>
+#include <atomic>
 #include <deque>
 #include <map>
 #include <mutex>
@@ -164,18 +166,127 @@ void ckpt_save(Table &T, u64 seed, u64 lcg) {
         remove(tpath.c_str());
 }
 
-// extends T.host to at least `want` checkpoints (T.mu held)
-void walk_to(Table &T, u64 want) {
-    if (T.host.size() >= want) return;
-    if (want > T.host.capacity()) { // grow the host copy geometrically (reserve alone would allocate exactly)
-        const u64 geo = T.host.capacity() + T.host.capacity() / 2;
-        T.host.reserve(want > geo ? want : geo);
-    }
+// ---- sparse marks: the state of a stream every MARK_STRIDE words, for the streams whose keys are compile-time
+// constants of the engines (and the benchmark's input streams), shipped beside the library as prg_marks.bin
+// (tools/make_prg_marks.cpp; MPCX_PRG_MARKS=<file> overrides, an empty value switches the marks off).  prvhash-core64
+// has no jump-ahead, so one stream is one serial chain (~1 ns per word on a host core: 5 s for the 2^32 words a
+// 2^24-element privateCompare reads); with the marks, the segments between them are walked on many threads at once.
+// Nothing in the file is trusted: mark 0 must be the state this process computes itself, and a segment walked from mark k
+// must end in mark k + 1 -- otherwise the parallel result is discarded and the serial walk takes over.
+struct Marks {
+    u64 stride = 0;
+    std::map<std::pair<u64, u64>, std::vector<PrgCk>> by_key;
+};
+const Marks &marks() {
+    static Marks M;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        std::string path;
+        const char *env = getenv("MPCX_PRG_MARKS");
+        if (env) {
+            path = env;
+        } else {
+            Dl_info info;
+            if (dladdr((const void *)&marks, &info) && info.dli_fname) {
+                path = info.dli_fname;
+                const size_t slash = path.rfind('/');
+                path = (slash == std::string::npos ? std::string(".") : path.substr(0, slash)) + "/prg_marks.bin";
+            }
+        }
+        if (path.empty()) return;
+        FILE *f = fopen(path.c_str(), "rb");
+        if (!f) return;
+        u64 hdr[3];
+        if (fread(hdr, 8, 3, f) == 3 && hdr[0] == 0x314B524D5843504Dull && hdr[1] >= PRG_CK && hdr[1] % PRG_CK == 0 &&
+            hdr[2] <= 64) {
+            Marks tmp;
+            tmp.stride = hdr[1];
+            bool ok = true;
+            for (u64 k = 0; k < hdr[2] && ok; k++) {
+                u64 kh[3];
+                ok = fread(kh, 8, 3, f) == 3 && kh[2] >= 1 && kh[2] <= (1u << 20);
+                if (!ok) break;
+                std::vector<PrgCk> v(kh[2]);
+                ok = fread(v.data(), sizeof(PrgCk), kh[2], f) == kh[2];
+                if (ok) tmp.by_key[std::make_pair(kh[0], kh[1])].swap(v);
+            }
+            if (ok) M = std::move(tmp);
+        }
+        fclose(f);
+    });
+    return M;
+}
+
+// extends T.host to at least `want` checkpoints, one after the other (T.mu held)
+void walk_serial(Table &T, u64 want) {
     PrgCk c = T.host.back();
     while (T.host.size() < want) {
         for (u64 i = 0; i < PRG_CK; i++) prv_step(c.seed, c.lcg, c.hash);
         T.host.push_back(c);
     }
+}
+// the same on several threads, segment by segment between the marks of the stream; false = nothing was changed
+bool walk_with_marks(Table &T, u64 seed, u64 lcg, u64 want) {
+    const Marks &M = marks();
+    if (!M.stride) return false;
+    const auto it = M.by_key.find(std::make_pair(seed, lcg));
+    if (it == M.by_key.end()) return false;
+    const std::vector<PrgCk> &mk = it->second;
+    const PrgCk &c0 = T.host[0];
+    if (mk[0].seed != c0.seed || mk[0].lcg != c0.lcg || mk[0].hash != c0.hash) return false;
+    const u64 per = M.stride / PRG_CK;                 // checkpoints per segment
+    const u64 have = T.host.size();                    // checkpoints 0 .. have - 1 exist
+    const u64 first = (have - 1 + per - 1) / per;      // first mark at or after the last checkpoint there is
+    u64 last = (want - 1) / per;                       // last mark at or before the last checkpoint wanted
+    if (last >= mk.size()) last = mk.size() - 1;
+    if (last <= first || last - first < 2) return false; // too little to share out
+    // the stretch before the first usable mark, serially (less than one segment)
+    walk_serial(T, first * per + 1);
+    const PrgCk &at = T.host[first * per];
+    if (at.seed != mk[first].seed || at.lcg != mk[first].lcg || at.hash != mk[first].hash) return false; // walked anyway
+    const u64 old_size = T.host.size();
+    T.host.resize(last * per + 1);
+    const u64 nseg = last - first;
+    unsigned nth = std::thread::hardware_concurrency();
+    nth = nth < 2 ? 2 : nth > 16 ? 16 : nth;
+    if (nth > nseg) nth = (unsigned)nseg;
+    std::atomic<u64> next{0};
+    std::atomic<bool> good{true};
+    auto work = [&] {
+        for (;;) {
+            const u64 k = next.fetch_add(1);
+            if (k >= nseg || !good.load()) return;
+            const u64 m = first + k;
+            PrgCk c = mk[m];
+            PrgCk *out = T.host.data() + m * per; // out[0] is mark m itself
+            out[0] = c;
+            for (u64 e = 1; e <= per; e++) {
+                for (u64 i = 0; i < PRG_CK; i++) prv_step(c.seed, c.lcg, c.hash);
+                if (e < per) out[e] = c;
+            }
+            if (c.seed != mk[m + 1].seed || c.lcg != mk[m + 1].lcg || c.hash != mk[m + 1].hash) good.store(false);
+        }
+    };
+    std::vector<std::thread> th;
+    for (unsigned i = 1; i < nth; i++) th.emplace_back(work);
+    work();
+    for (auto &t : th) t.join();
+    if (!good.load()) { // a mark does not follow from the one before it: keep only what was walked serially
+        T.host.resize(old_size);
+        return false;
+    }
+    T.host[last * per] = mk[last];
+    return true;
+}
+// extends T.host to at least `want` checkpoints (T.mu held)
+void walk_to(Table &T, u64 want, u64 seed = 0, u64 lcg = 0, bool keyed = false) {
+    if (T.host.size() >= want) return;
+    if (want > T.host.capacity()) { // grow the host copy geometrically (reserve alone would allocate exactly)
+        const u64 geo = T.host.capacity() + T.host.capacity() / 2;
+        T.host.reserve(want > geo ? want : geo);
+    }
+    if (keyed && want - T.host.size() >= (1u << 17)) (void)walk_with_marks(T, seed, lcg, want); // 2^23 words and more
+    walk_serial(T, want);
 }
 // mirrors T.host on the device (T.mu held, the device current); returns a hipError_t
 hipError_t upload(Table &T) {
@@ -392,7 +503,7 @@ static int prg_table(mpcx_ctx *ctx, u64 seed, u64 lcg, u64 t_end, const PrgCk **
         // many calls
         u64 ahead = need / 8;
         ahead = ahead < 4096 ? 4096 : ahead > 65536 ? 65536 : ahead;
-        walk_to(T, need + ahead);
+        walk_to(T, need + ahead, seed, lcg, true);
         if (save_now || !walker_enabled())
             ckpt_save(T, seed, lcg);
         else

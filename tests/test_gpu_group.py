@@ -241,6 +241,39 @@ def test_checkpoint_cache_default_directory(tmp_path):
     assert r.returncode == 0 and not (tmp_path / "xdg2" / "mpcx").exists()
 
 
+def test_sparse_marks_parallel_walk_is_exact_and_not_trusted(tmp_path):
+    """The library walks a long stream on many host threads between the sparse marks shipped beside it
+    (mpc_amd/prg_marks.bin).  The words far into the KEY01 stream (buffer index 2^27, stream word 2^28) are the oracle's
+    with the marks, without them (MPCX_PRG_MARKS empty: the serial walk), and with a marks file in which one state was
+    damaged (a segment then does not end where the next mark says, and the serial walk takes over)."""
+    import sys
+    from oracle_lib import prg_buff
+    first, count = (1 << 27) - 500, 1000
+    prog = ("import sys, time, numpy as np; sys.path.insert(0, %r); from mpc_amd import Context; c = Context(0); "
+            "t0 = time.perf_counter(); c.call('prg_ckpt_build', 0xAB01, 0, 0, %d); dt = time.perf_counter() - t0; "
+            "d = c.empty(np.int64, %d); b = c.empty(np.int8, %d); c.call('prg_fill_buff', 0xAB01, 0, %d, %d, d, b); c.sync(); "
+            "print('WALK_S', dt); print('WORDS', ' '.join('%%x' %% (int(v) & (2**64 - 1)) for v in d.to_host()), "
+            "''.join(str(int(v)) for v in b.to_host()))" % (ROOT, first + count, count, count, first, count))
+    base = dict(os.environ, MPCX_CKPT_CACHE="", MPCX_PRG_WALK_AHEAD="0")
+    run = lambda e: subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=300, env=e)
+    words = lambda r: [l for l in r.stdout.splitlines() if l.startswith("WORDS")][0]
+    secs = lambda r: float([l for l in r.stdout.splitlines() if l.startswith("WALK_S")][0].split()[1])
+    with_marks = run({k: v for k, v in base.items() if k != "MPCX_PRG_MARKS"})
+    assert with_marks.returncode == 0, with_marks.stderr[-2000:]
+    ints, bools = prg_buff(0xAB01, first, count)
+    want = "WORDS " + " ".join("%x" % (int(v) & (2 ** 64 - 1)) for v in ints) + " " + "".join(str(int(v)) for v in bools)
+    assert words(with_marks) == want
+    serial = run(dict(base, MPCX_PRG_MARKS=""))
+    assert serial.returncode == 0 and words(serial) == want
+    data = bytearray(open(os.path.join(ROOT, "mpc_amd", "prg_marks.bin"), "rb").read())
+    data[24 + 24 + 24 * 10 + 5] ^= 0x40  # the first table is KEY01's: its mark 10
+    bad = tmp_path / "marks.bin"
+    bad.write_bytes(bytes(data))
+    damaged = run(dict(base, MPCX_PRG_MARKS=str(bad)))
+    assert damaged.returncode == 0 and words(damaged) == want
+    assert secs(with_marks) < secs(serial), (secs(with_marks), secs(serial))
+
+
 @pytest.mark.parametrize("nbytes", [1, 4095, (4 << 20) - 1, 4 << 20, (4 << 20) + 1, (12 << 20) - 3, (37 << 20) + 5])
 def test_host_device_copies_round_trip(nbytes):
     """mpcx_h2d / mpcx_d2h (plain below 4 MiB, pipelined through the pinned staging buffers above, ragged last chunks)
