@@ -145,3 +145,25 @@ def test_host_engines_with_protocol_self_checks():
     plain = subprocess.run([os.path.join(HOST, "host_selftest")], capture_output=True, text=True, timeout=300)
     kat = lambda out: sorted(l for l in out.splitlines() if l.startswith("KAT "))
     assert kat(r.stdout) == kat(plain.stdout) and kat(r.stdout)
+
+
+@pytest.mark.gpu
+def test_three_processes_over_socket_messenger():
+    """The reference's own process model (benchmark/makefile:13-17: `./benchmark1 0 &`, `1 &`, `2`): three single-party
+    processes over the wire-compatible SocketMessenger (127.0.0.1, ports 8000-8002), every engine on the one GPU.  Each
+    process checks every result against the plain computation."""
+    exe = os.path.join(HOST, "benchmark1")
+    assert os.path.exists(exe), "mpc_amd/host/benchmark1 missing: run __graft_entry__.build()"
+    args = ["--width", "96", "--vec", "3000", "--repeat", "1"]
+    procs = [subprocess.Popen([exe, str(p)] + args, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for p in range(3)]
+    outs = []
+    try:
+        for pr_ in procs:
+            outs.append(pr_.communicate(timeout=240)[0])
+    finally:
+        for pr_ in procs:
+            if pr_.poll() is None:
+                pr_.kill()
+    for p, (pr_, out) in enumerate(zip(procs, outs)):
+        assert pr_.returncode == 0 and "all results verified" in out, f"party {p}: {out[-2000:]}"
