@@ -409,6 +409,18 @@ int mpcx_group_for_each(mpcx_group *g, uint64_t n, uint64_t granule, mpcx_member
 int mpcx_group_aby3_matmul_local(mpcx_group *g, const int64_t *X0, const int64_t *X1, const int64_t *Y0,
                                  const int64_t *Y1, uint64_t r, uint64_t l, uint64_t c, int layout, uint64_t seed_next,
                                  uint64_t pop_next, uint64_t seed_prev, uint64_t pop_prev, int64_t *Z0);
+/* A replicated operand kept on the members' devices: every member uploads both shares of Y (rows x cols, `layout`) once
+ * and keeps a row-major copy until mpcx_group_operand_free; mpcx_group_aby3_matmul_local_resident is
+ * mpcx_group_aby3_matmul_local with that operand in place of the host pointers Y0 / Y1, so that a product moves only the
+ * members' row blocks of X and Z (a weight matrix used by many products; for the 16384 x 16384 configuration Y is 4 GiB
+ * per member and call otherwise).  No counterpart in the reference. */
+typedef struct mpcx_group_operand mpcx_group_operand;
+int mpcx_group_operand_upload(mpcx_group *g, const int64_t *M0, const int64_t *M1, uint64_t rows, uint64_t cols, int layout,
+                              mpcx_group_operand **out);
+int mpcx_group_operand_free(mpcx_group *g, mpcx_group_operand *op);
+int mpcx_group_aby3_matmul_local_resident(mpcx_group *g, const int64_t *X0, const int64_t *X1, const mpcx_group_operand *Y,
+                                          uint64_t r, uint64_t l, uint64_t c, int layout, uint64_t seed_next,
+                                          uint64_t pop_next, uint64_t seed_prev, uint64_t pop_prev, int64_t *Z0);
 /* mpcx_snn_beaver_party_finish_matmul (SecurennEngine.cpp:157-167) over the group.  triple (A | B | C), ef_own and ef_peer
  * (E | F) are HOST pointers in the wire order of the messages that carry them, Z (r x c, row-major) a host pointer:
  * every member uploads its rows of A, C and E and all of B and F, and writes its rows of Z into place. */

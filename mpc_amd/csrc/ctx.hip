@@ -354,6 +354,42 @@ int mpcx_h2d(mpcx_ctx *ctx, void *dst, const void *src, uint64_t bytes) {
     MPCX_HIP(hipStreamSynchronize(ctx->stream)); // the host buffer may be pageable and reused at once
     return 0;
 }
+} // extern "C"
+// `height` runs of `width` bytes that lie `spitch` bytes apart in pageable host memory -> one contiguous device buffer
+// (a row block of a column-major matrix: `rows` consecutive words in each column).  The runs are gathered into the
+// pinned staging buffers by the host threads, whole runs per chunk, and leave from there like mpcx_h2d's chunks; a
+// run longer than a staging buffer goes through mpcx_h2d by itself.
+int mpcx_h2d_gather(mpcx_ctx *ctx, void *dst, const void *src, u64 spitch, u64 width, u64 height) {
+    MPCX_REQUIRE(ctx, "mpcx_h2d_gather: the context is NULL (already shut down?)");
+    if (!width || !height) return 0;
+    if (width == spitch) return mpcx_h2d(ctx, dst, src, width * height);
+    if (width > kStageChunk) {
+        for (u64 h = 0; h < height; h++)
+            MPCX_TRY(mpcx_h2d(ctx, (char *)dst + h * width, (const char *)src + h * spitch, width));
+        return 0;
+    }
+    CopyTimer timer(0, width * height);
+    MPCX_TRY(stage_setup(ctx));
+    const u64 per = kStageChunk / width; // runs per chunk
+    u64 k = 0;
+    for (u64 h0 = 0; h0 < height; h0 += per, k++) {
+        const u64 cnt = height - h0 < per ? height - h0 : per;
+        if (k >= 2) MPCX_HIP(hipEventSynchronize(ctx->stage_ev[k & 1])); // its previous chunk has left the buffer
+        char *stage = (char *)ctx->stage[k & 1];
+        const char *from = (const char *)src + h0 * spitch;
+        const u64 pieces = cnt * width < (1u << 16) ? 1 : copy_pool().threads + 1;
+        const u64 share = (cnt + pieces - 1) / pieces;
+        pool_run(pieces, [=](u64 piece) {
+            const u64 lo = piece * share, hi = lo + share < cnt ? lo + share : cnt;
+            for (u64 h = lo; h < hi; h++) memcpy(stage + h * width, from + h * spitch, width);
+        });
+        MPCX_HIP(hipMemcpyAsync((char *)dst + h0 * width, stage, cnt * width, hipMemcpyHostToDevice, ctx->stream));
+        MPCX_HIP(hipEventRecord(ctx->stage_ev[k & 1], ctx->stream));
+    }
+    MPCX_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+extern "C" {
 int mpcx_d2h(mpcx_ctx *ctx, void *dst, const void *src, uint64_t bytes) {
     MPCX_REQUIRE(ctx, "mpcx_d2h: the context is NULL (already shut down?)");
     if (!bytes) return 0;

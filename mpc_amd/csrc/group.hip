@@ -27,6 +27,13 @@ struct mpcx_group {
     std::vector<std::unique_ptr<Worker>> workers;
 };
 
+// A replicated operand of matrix products (both shares of Y, row-major) that every member of a group holds on its
+// device from mpcx_group_operand_upload until mpcx_group_operand_free.
+struct mpcx_group_operand {
+    u64 rows, cols;
+    std::vector<void *> s0, s1; // per member
+};
+
 namespace {
 
 void worker_main(mpcx_group::Worker *w, int device) {
@@ -163,13 +170,11 @@ int mpcx_group_for_each(mpcx_group *g, uint64_t n, uint64_t granule, mpcx_member
     });
 }
 
-int mpcx_group_aby3_matmul_local(mpcx_group *g, const int64_t *X0, const int64_t *X1, const int64_t *Y0,
-                                 const int64_t *Y1, uint64_t r, uint64_t l, uint64_t c, int layout, uint64_t seed_next,
-                                 uint64_t pop_next, uint64_t seed_prev, uint64_t pop_prev, int64_t *Z0) {
-    if (!g) return group_fail(g, "mpcx_group_aby3_matmul_local: the group is NULL");
-    if (!(X0 && X1 && Y0 && Y1 && Z0)) return group_fail(g, "mpcx_group_aby3_matmul_local: NULL operand");
-    if (!(r && l && c)) return group_fail(g, "mpcx_group_aby3_matmul_local: empty shape");
-    if (layout != 0 && layout != 1) return group_fail(g, "mpcx_group_aby3_matmul_local: layout must be 0 or 1");
+// the common part of the two forms below: op == NULL uploads Y0 / Y1 (host) per call, otherwise the members' resident
+// copies are used
+static int group_aby3_matmul(mpcx_group *g, const int64_t *X0, const int64_t *X1, const int64_t *Y0, const int64_t *Y1,
+                             const mpcx_group_operand *op, uint64_t r, uint64_t l, uint64_t c, int layout,
+                             uint64_t seed_next, uint64_t pop_next, uint64_t seed_prev, uint64_t pop_prev, int64_t *Z0) {
     int members = (int)g->ctx.size();
     const u64 granule = 128; // rows of a block tile of the digit-pair kernel
     if (ceil_div(r, granule) < (u64)members) members = (int)ceil_div(r, granule);
@@ -190,40 +195,112 @@ int mpcx_group_aby3_matmul_local(mpcx_group *g, const int64_t *X0, const int64_t
     } while (0)
         G_TRY(mpcx_malloc(ctx, 8 * rows * l, &px0));
         G_TRY(mpcx_malloc(ctx, 8 * rows * l, &px1));
-        G_TRY(mpcx_malloc(ctx, 8 * l * c, &py0));
-        G_TRY(mpcx_malloc(ctx, 8 * l * c, &py1));
+        if (!op) {
+            G_TRY(mpcx_malloc(ctx, 8 * l * c, &py0));
+            G_TRY(mpcx_malloc(ctx, 8 * l * c, &py1));
+        }
         G_TRY(mpcx_malloc(ctx, 8 * rows * c, &pz));
         if (layout == 0) {
             G_TRY(mpcx_h2d(ctx, px0, X0 + row0 * l, 8 * rows * l));
             G_TRY(mpcx_h2d(ctx, px1, X1 + row0 * l, 8 * rows * l));
-            G_TRY(mpcx_h2d(ctx, py0, Y0, 8 * l * c));
-            G_TRY(mpcx_h2d(ctx, py1, Y1, 8 * l * c));
+            if (!op) {
+                G_TRY(mpcx_h2d(ctx, py0, Y0, 8 * l * c));
+                G_TRY(mpcx_h2d(ctx, py1, Y1, 8 * l * c));
+            }
         } else {
             // column-major operands (how Eigen stores MatrixXl): the member's rows of X are a strided slab on the host --
-            // `rows` consecutive words in each of the l columns -- which one 2-D copy brings up as a rows x l
-            // column-major block; it is turned on the device.  Only the member's share of X crosses the link.
-            const u64 big = rows * l > l * c ? rows * l : l * c;
+            // `rows` consecutive words in each of the l columns -- which the host threads gather into the pinned staging
+            // buffers as a rows x l column-major block; it is turned on the device.  Only the member's share of X
+            // crosses the link.  (A 2-D hipMemcpy from pageable memory is not used: several host threads issuing it
+            // beside staged copies of other contexts did not return.)
+            const u64 big = (op || rows * l > l * c) ? rows * l : l * c;
             G_TRY(mpcx_malloc(ctx, 8 * big, &tmp));
             for (int s = 0; s < 2; s++) {
                 const i64 *src = (s ? X1 : X0) + row0;
-                if (hipMemcpy2DAsync(tmp, 8 * rows, src, 8 * r, 8 * rows, l, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
-                    hipStreamSynchronize(ctx->stream) != hipSuccess) {
-                    mpcx_fail(ctx, "mpcx_group_aby3_matmul_local: the copy of a row block failed");
-                    return release(1);
-                }
+                G_TRY(mpcx_h2d_gather(ctx, tmp, src, 8 * r, 8 * rows, l));
                 G_TRY(mpcx_relayout(ctx, (const i64 *)tmp, (i64 *)(s ? px1 : px0), rows, l, 1, 0));
             }
-            G_TRY(mpcx_h2d(ctx, tmp, Y0, 8 * l * c));
-            G_TRY(mpcx_relayout(ctx, (const i64 *)tmp, (i64 *)py0, l, c, 1, 0));
-            G_TRY(mpcx_h2d(ctx, tmp, Y1, 8 * l * c));
-            G_TRY(mpcx_relayout(ctx, (const i64 *)tmp, (i64 *)py1, l, c, 1, 0));
+            if (!op) {
+                G_TRY(mpcx_h2d(ctx, tmp, Y0, 8 * l * c));
+                G_TRY(mpcx_relayout(ctx, (const i64 *)tmp, (i64 *)py0, l, c, 1, 0));
+                G_TRY(mpcx_h2d(ctx, tmp, Y1, 8 * l * c));
+                G_TRY(mpcx_relayout(ctx, (const i64 *)tmp, (i64 *)py1, l, c, 1, 0));
+            }
         }
-        G_TRY(mpcx_aby3_matmul_local_rows(ctx, (const i64 *)px0, (const i64 *)px1, (const i64 *)py0, (const i64 *)py1, rows,
-                                          l, c, row0, seed_next, pop_next, seed_prev, pop_prev, (i64 *)pz));
+        const i64 *y0 = op ? (const i64 *)op->s0[k] : (const i64 *)py0, *y1 = op ? (const i64 *)op->s1[k] : (const i64 *)py1;
+        G_TRY(mpcx_aby3_matmul_local_rows(ctx, (const i64 *)px0, (const i64 *)px1, y0, y1, rows, l, c, row0, seed_next,
+                                          pop_next, seed_prev, pop_prev, (i64 *)pz));
         G_TRY(mpcx_d2h(ctx, Z0 + row0 * c, pz, 8 * rows * c)); // straight into the caller's (messenger-facing) buffer
 #undef G_TRY
         return release(0);
     });
+}
+
+int mpcx_group_aby3_matmul_local(mpcx_group *g, const int64_t *X0, const int64_t *X1, const int64_t *Y0,
+                                 const int64_t *Y1, uint64_t r, uint64_t l, uint64_t c, int layout, uint64_t seed_next,
+                                 uint64_t pop_next, uint64_t seed_prev, uint64_t pop_prev, int64_t *Z0) {
+    if (!g) return group_fail(g, "mpcx_group_aby3_matmul_local: the group is NULL");
+    if (!(X0 && X1 && Y0 && Y1 && Z0)) return group_fail(g, "mpcx_group_aby3_matmul_local: NULL operand");
+    if (!(r && l && c)) return group_fail(g, "mpcx_group_aby3_matmul_local: empty shape");
+    if (layout != 0 && layout != 1) return group_fail(g, "mpcx_group_aby3_matmul_local: layout must be 0 or 1");
+    return group_aby3_matmul(g, X0, X1, Y0, Y1, nullptr, r, l, c, layout, seed_next, pop_next, seed_prev, pop_prev, Z0);
+}
+
+int mpcx_group_aby3_matmul_local_resident(mpcx_group *g, const int64_t *X0, const int64_t *X1,
+                                          const mpcx_group_operand *Y, uint64_t r, uint64_t l, uint64_t c, int layout,
+                                          uint64_t seed_next, uint64_t pop_next, uint64_t seed_prev, uint64_t pop_prev,
+                                          int64_t *Z0) {
+    if (!g) return group_fail(g, "mpcx_group_aby3_matmul_local_resident: the group is NULL");
+    if (!(X0 && X1 && Y && Z0)) return group_fail(g, "mpcx_group_aby3_matmul_local_resident: NULL operand");
+    if (!(r && l && c)) return group_fail(g, "mpcx_group_aby3_matmul_local_resident: empty shape");
+    if (layout != 0 && layout != 1) return group_fail(g, "mpcx_group_aby3_matmul_local_resident: layout must be 0 or 1");
+    if (Y->rows != l || Y->cols != c || Y->s0.size() != g->ctx.size())
+        return group_fail(g, "mpcx_group_aby3_matmul_local_resident: the operand is %llu x %llu on %zu members, the product "
+                             "needs %llu x %llu on %zu", (unsigned long long)Y->rows, (unsigned long long)Y->cols,
+                          Y->s0.size(), (unsigned long long)l, (unsigned long long)c, g->ctx.size());
+    return group_aby3_matmul(g, X0, X1, nullptr, nullptr, Y, r, l, c, layout, seed_next, pop_next, seed_prev, pop_prev, Z0);
+}
+
+int mpcx_group_operand_upload(mpcx_group *g, const int64_t *M0, const int64_t *M1, uint64_t rows, uint64_t cols, int layout,
+                              mpcx_group_operand **out) {
+    if (!g || !out) return group_fail(g, "mpcx_group_operand_upload: NULL argument");
+    if (!(M0 && M1 && rows && cols)) return group_fail(g, "mpcx_group_operand_upload: NULL or empty operand");
+    if (layout != 0 && layout != 1) return group_fail(g, "mpcx_group_operand_upload: layout must be 0 or 1");
+    const int members = (int)g->ctx.size();
+    mpcx_group_operand *op = new mpcx_group_operand();
+    op->rows = rows, op->cols = cols;
+    op->s0.assign(members, nullptr);
+    op->s1.assign(members, nullptr);
+    const int rc = group_run(g, members, [=](int k) -> int {
+        mpcx_ctx *ctx = g->ctx[k];
+        void *tmp = nullptr;
+        if (mpcx_malloc(ctx, 8 * rows * cols, &op->s0[k]) || mpcx_malloc(ctx, 8 * rows * cols, &op->s1[k])) return 1;
+        if (layout == 0) return mpcx_h2d(ctx, op->s0[k], M0, 8 * rows * cols) || mpcx_h2d(ctx, op->s1[k], M1, 8 * rows * cols);
+        if (mpcx_malloc(ctx, 8 * rows * cols, &tmp)) return 1;
+        int rc2 = mpcx_h2d(ctx, tmp, M0, 8 * rows * cols);
+        if (!rc2) rc2 = mpcx_relayout(ctx, (const i64 *)tmp, (i64 *)op->s0[k], rows, cols, 1, 0);
+        if (!rc2) rc2 = mpcx_h2d(ctx, tmp, M1, 8 * rows * cols); // ordered behind the relayout on the context's stream
+        if (!rc2) rc2 = mpcx_relayout(ctx, (const i64 *)tmp, (i64 *)op->s1[k], rows, cols, 1, 0);
+        (void)mpcx_free(ctx, tmp);
+        return rc2;
+    });
+    if (rc) {
+        (void)mpcx_group_operand_free(g, op);
+        return rc;
+    }
+    *out = op;
+    return 0;
+}
+
+int mpcx_group_operand_free(mpcx_group *g, mpcx_group_operand *op) {
+    if (!op) return 0;
+    if (g)
+        for (size_t k = 0; k < op->s0.size() && k < g->ctx.size(); k++) {
+            (void)mpcx_free(g->ctx[k], op->s0[k]);
+            (void)mpcx_free(g->ctx[k], op->s1[k]);
+        }
+    delete op;
+    return 0;
 }
 
 

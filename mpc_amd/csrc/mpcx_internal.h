@@ -69,6 +69,8 @@ struct mpcx_ctx {
 int mpcx_fail(mpcx_ctx *ctx, const char *fmt, ...);
 // memcpy cut into pieces moved by the library's pool of host threads (MPCX_COPY_THREADS; default half the hardware threads, 4 to 16) and the caller
 void mpcx_parallel_memcpy(void *dst, const void *src, u64 bytes);
+// strided runs of pageable host memory -> contiguous device memory, through the pinned staging buffers (ctx.hip)
+int mpcx_h2d_gather(mpcx_ctx *ctx, void *dst, const void *src, u64 spitch, u64 width, u64 height);
 // scratch of at least `bytes`, 256-byte aligned, valid until the next mpcx_ws call on this context
 int mpcx_ws(mpcx_ctx *ctx, u64 bytes, void **out);
 // device pointer to the checkpoint table of (seed,lcg) covering stream words [0, t_end)

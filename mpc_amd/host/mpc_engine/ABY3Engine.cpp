@@ -25,14 +25,28 @@ ABY3Engine::ABY3Engine(VirtuleMessenger *_messenger, size_t _party_id) : messeng
     gpu = group ? mpcx_group_ctx(group, 0) : mpcgpu::open_context();
 }
 
-// a share pair kept on the engine's first GPU, column-major as Eigen stores it
+// a share pair kept on the device, column-major as Eigen stores it -- or, for an engine that spreads its products over a
+// group of GPUs, a row-major copy on every member (mpcx_group_operand: the replicated second operand of matrix_mul)
 struct ABY3Engine::Pinned {
     const MatPair *key;
     size_t rows, cols;
-    Dev<int64_t> s0, s1;
-    Pinned(mpcx_ctx *ctx, const MatPair &M)
-        : key(&M), rows(M[0].rows()), cols(M[0].cols()), s0(ctx, M[0].data(), M[0].rows() * M[0].cols()),
-          s1(ctx, M[1].data(), M[1].rows() * M[1].cols()) {}
+    std::unique_ptr<Dev<int64_t>> s0, s1;
+    mpcx_group *group = nullptr;
+    mpcx_group_operand *gop = nullptr;
+    Pinned(mpcx_ctx *ctx, mpcx_group *g, const MatPair &M) : key(&M), rows(M[0].rows()), cols(M[0].cols()), group(g) {
+        if (group) {
+            if (mpcx_group_operand_upload(group, M[0].data(), M[1].data(), rows, cols, 1, &gop) != 0) {
+                fprintf(stderr, "mpcx_group_operand_upload: %s\n", mpcx_group_last_error(group));
+                abort();
+            }
+        } else {
+            s0.reset(new Dev<int64_t>(ctx, M[0].data(), rows * cols));
+            s1.reset(new Dev<int64_t>(ctx, M[1].data(), rows * cols));
+        }
+    }
+    ~Pinned() {
+        if (gop) mpcx_group_operand_free(group, gop);
+    }
 };
 ABY3Engine::Pinned *ABY3Engine::find_pinned(const MatPair &M) const {
     for (Pinned *p : pinned)
@@ -42,7 +56,7 @@ ABY3Engine::Pinned *ABY3Engine::find_pinned(const MatPair &M) const {
 void ABY3Engine::pin(const MatPair &M) {
     assert(M[0].rows() == M[1].rows() && M[0].cols() == M[1].cols());
     unpin(M);
-    pinned.push_back(new Pinned(gpu, M));
+    if (M[0].rows() && M[0].cols()) pinned.push_back(new Pinned(gpu, group, M));
 }
 void ABY3Engine::unpin(const MatPair &M) {
     for (size_t i = 0; i < pinned.size(); i++)
@@ -348,11 +362,20 @@ void ABY3Engine::matrix_mul(const array<MatrixXl, 2> &Xj, const array<MatrixXl, 
     assert(Yj[1].rows() == lens && Yj[1].cols() == cols);
     message_send[pe.next].clear();
     if (group && rows && lens && cols) {
-        // row blocks over the group's GPUs, each written into its place of the outgoing message
+        // row blocks over the group's GPUs, each written into its place of the outgoing message; a pinned second operand
+        // is on every member already
         message_send[pe.prev].resize(rows * cols * sizeof(int64_t));
-        if (mpcx_group_aby3_matmul_local(group, Xj[0].data(), Xj[1].data(), Yj[0].data(), Yj[1].data(), rows, lens, cols, 1,
-                                         prgs[pe.next].init_seed, prgs[pe.next].pops, prgs[pe.prev].init_seed,
-                                         prgs[pe.prev].pops, (int64_t *)&message_send[pe.prev][0]) != 0) {
+        const Pinned *py = find_pinned(Yj);
+        assert(!py || (py->rows == lens && py->cols == cols));
+        const int rc = py ? mpcx_group_aby3_matmul_local_resident(group, Xj[0].data(), Xj[1].data(), py->gop, rows, lens, cols, 1,
+                                                                  prgs[pe.next].init_seed, prgs[pe.next].pops,
+                                                                  prgs[pe.prev].init_seed, prgs[pe.prev].pops,
+                                                                  (int64_t *)&message_send[pe.prev][0])
+                          : mpcx_group_aby3_matmul_local(group, Xj[0].data(), Xj[1].data(), Yj[0].data(), Yj[1].data(), rows,
+                                                         lens, cols, 1, prgs[pe.next].init_seed, prgs[pe.next].pops,
+                                                         prgs[pe.prev].init_seed, prgs[pe.prev].pops,
+                                                         (int64_t *)&message_send[pe.prev][0]);
+        if (rc != 0) {
             fprintf(stderr, "mpcx_group_aby3_matmul_local: %s\n", mpcx_group_last_error(group));
             abort();
         }
@@ -372,8 +395,8 @@ void ABY3Engine::matrix_mul(const array<MatrixXl, 2> &Xj, const array<MatrixXl, 
             uy0.reset(new Dev<int64_t>(gpu, Yj[0].data(), lens * cols));
             uy1.reset(new Dev<int64_t>(gpu, Yj[1].data(), lens * cols));
         }
-        const int64_t *x0 = px ? px->s0.p : ux0->p, *x1 = px ? px->s1.p : ux1->p;
-        const int64_t *y0 = py ? py->s0.p : uy0->p, *y1 = py ? py->s1.p : uy1->p;
+        const int64_t *x0 = px ? px->s0->p : ux0->p, *x1 = px ? px->s1->p : ux1->p;
+        const int64_t *y0 = py ? py->s0->p : uy0->p, *y1 = py ? py->s1->p : uy1->p;
         up.reset();
         // Eigen stores column-major (layout 1); the result comes back row-major = the wire order
         {

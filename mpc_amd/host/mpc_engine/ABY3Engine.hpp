@@ -86,7 +86,8 @@ class ABY3Engine {
     void relu(const VecPair &X, VecPair &R);
     // Keeps a device copy of a share pair (e.g. a weight matrix that many products use) until unpin: matrix_mul finds
     // an operand by the address of its pair and skips the upload.  Explicit on purpose: the caller promises not to
-    // change or destroy a pinned pair.  The destructor releases what is still pinned.
+    // change or destroy a pinned pair.  The destructor releases what is still pinned.  With MPCX_DEVICES every GPU of
+    // the group keeps a copy, and matrix_mul uses it for its second (replicated) operand.
     void pin(const MatPair &M);
     void unpin(const MatPair &M);
 

@@ -30,7 +30,8 @@ def ptr(a):
 
 
 @pytest.mark.parametrize("members", [1, 2, 3])
-@pytest.mark.parametrize("r,l,c,layout", [(300, 70, 130, 0), (300, 70, 130, 1), (5, 4, 3, 1), (1000, 260, 520, 0)])
+@pytest.mark.parametrize("r,l,c,layout", [(300, 70, 130, 0), (300, 70, 130, 1), (5, 4, 3, 1), (1000, 260, 520, 0),
+                                          (2048, 1024, 512, 1)])  # the last: operands beyond the staged-copy threshold
 def test_group_matmul_equals_the_oracle(lib, orc, members, r, l, c, layout):
     """mpcx_group_aby3_matmul_local on host operands: the row blocks of the members, each written into its place
     of Z0, are the whole product + mask of the CPU oracle (both operand layouts)."""
@@ -46,6 +47,36 @@ def test_group_matmul_equals_the_oracle(lib, orc, members, r, l, c, layout):
                                               U64(KEY01), U64(11), U64(KEY20), U64(7), ptr(Z))
         assert rc == 0, lib.mpcx_group_last_error(g)
         assert np.array_equal(Z, orc.aby3_matmul_local(X0, X1, Y0, Y1, r, l, c, layout, KEY01, 11, KEY20, 7))
+    finally:
+        lib.mpcx_group_shutdown(g)
+
+
+@pytest.mark.parametrize("members", [1, 3])
+@pytest.mark.parametrize("r,l,c,layout", [(300, 70, 130, 0), (300, 70, 130, 1), (1000, 260, 520, 1)])
+def test_group_matmul_with_a_resident_operand(lib, orc, members, r, l, c, layout):
+    """mpcx_group_operand_upload keeps both shares of Y on every member; two products with different X and different
+    stream offsets through mpcx_group_aby3_matmul_local_resident are the oracle's (and so the per-call form's); an
+    operand of another shape is refused."""
+    g = ctypes.c_void_p()
+    assert lib.mpcx_group_init((I32 * members)(*([0] * members)), I32(members), ctypes.byref(g)) == 0
+    try:
+        rng = np.random.default_rng(r * 17 + members + layout)
+        Y0, Y1 = (rng.integers(-2 ** 63, 2 ** 63, l * c, dtype=np.int64) for _ in range(2))
+        op = ctypes.c_void_p()
+        assert lib.mpcx_group_operand_upload(g, ptr(Y0), ptr(Y1), U64(l), U64(c), I32(layout), ctypes.byref(op)) == 0, \
+            lib.mpcx_group_last_error(g)
+        for pop in (11, 12345):
+            X0, X1 = (rng.integers(-2 ** 63, 2 ** 63, r * l, dtype=np.int64) for _ in range(2))
+            Z = np.zeros(r * c, dtype=np.int64)
+            rc = lib.mpcx_group_aby3_matmul_local_resident(g, ptr(X0), ptr(X1), op, U64(r), U64(l), U64(c), I32(layout),
+                                                           U64(KEY01), U64(pop), U64(KEY20), U64(pop + 3), ptr(Z))
+            assert rc == 0, lib.mpcx_group_last_error(g)
+            assert np.array_equal(Z, orc.aby3_matmul_local(X0, X1, Y0, Y1, r, l, c, layout, KEY01, pop, KEY20, pop + 3))
+        Z = np.zeros(r * (c + 1), dtype=np.int64)
+        assert lib.mpcx_group_aby3_matmul_local_resident(g, ptr(X0), ptr(X1), op, U64(r), U64(l), U64(c + 1), I32(layout),
+                                                         U64(KEY01), U64(0), U64(KEY20), U64(0), ptr(Z)) != 0
+        assert b"operand is" in lib.mpcx_group_last_error(g)
+        assert lib.mpcx_group_operand_free(g, op) == 0
     finally:
         lib.mpcx_group_shutdown(g)
 
@@ -170,6 +201,18 @@ def test_host_benchmark_over_a_group_verifies():
     assert os.path.exists(exe), "mpc_amd/host/benchmark1 missing: run __graft_entry__.build()"
     r = subprocess.run([exe, "--engine", "aby3", "--width", "512", "--vec", "100000", "--repeat", "1", "--no-mlp"],
                        capture_output=True, text=True, timeout=600, env=dict(os.environ, MPCX_DEVICES="0,0"))
+    assert r.returncode == 0 and "all results verified" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+@pytest.mark.parametrize("pin", [False, True])
+def test_host_benchmark_over_a_group_with_staged_operands(pin):
+    """The same at 2048 x 2048 (operands of 32 MiB: every upload goes through the pinned staging buffers, a member's row
+    block of the column-major X is gathered by the host threads), three party threads with a group of two each, with
+    the second operand uploaded per call and resident on the members (ABY3Engine::pin)."""
+    exe = os.path.join(HOST, "benchmark1")
+    assert os.path.exists(exe), "mpc_amd/host/benchmark1 missing: run __graft_entry__.build()"
+    args = [exe, "--engine", "aby3", "--width", "2048", "--vec", "4096", "--repeat", "1", "--no-mlp"] + (["--pin"] if pin else [])
+    r = subprocess.run(args, capture_output=True, text=True, timeout=180, env=dict(os.environ, MPCX_DEVICES="0,0"))
     assert r.returncode == 0 and "all results verified" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
 
 
