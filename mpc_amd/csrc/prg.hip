@@ -153,6 +153,9 @@ void ckpt_load(Table &T, u64 seed, u64 lcg) {
 void ckpt_save(Table &T, u64 seed, u64 lcg) {
     const std::string path = ckpt_path(seed, lcg);
     if (path.empty() || T.host.size() <= T.saved_to_disk + T.saved_to_disk / 4 + 4096) return;
+    // in the implicit directory (nobody asked for a cache) tables beyond 256 MiB stay in memory only: with the sparse
+    // marks a long stream is walked about as fast as such a file is read, and a home directory is no place for gigabytes
+    if (!getenv("MPCX_CKPT_CACHE") && T.host.size() * sizeof(PrgCk) > (256ull << 20)) return;
     char tmp[32];
     snprintf(tmp, sizeof tmp, ".tmp.%ld", (long)getpid());
     const std::string tpath = path + tmp;
