@@ -376,6 +376,20 @@ static void aby3_additions_party(InProcHub *hub, size_t p) {
     for (size_t i = 0; i < n; i++) CHECK(Rr[i] == (X[i] < 0 ? 0 : X[i]));
     printf("KAT aby3_relu_fused_3001_R0 %zu %016lX\n", p, (unsigned long)fnv(R2[0].data(), n));
     {
+        // ragged and tiny vectors (fewer elements than one 64-element range, none at all)
+        ABY3Engine e(&msgr, p);
+        for (size_t m : {(size_t)0, (size_t)1, (size_t)63, (size_t)65, (size_t)130}) {
+            VecI64 Y(m), Yr;
+            for (size_t i = 0; i < m; i++) Y[i] = g.pop_int64();
+            array<VecI64, 2> Yj, Rj;
+            e.share(Y, Yj);
+            e.relu(Yj, Rj);
+            e.reveal(Rj, Yr);
+            CHECK((size_t)Yr.size() == m);
+            for (size_t i = 0; i < m; i++) CHECK(Yr[i] == (Y[i] < 0 ? 0 : Y[i]));
+        }
+    }
+    {
         ABY3Engine e(&msgr, p);
         PRgenerator h(32, 0);
         MatrixXl A(37, 50), B(50, 29);
@@ -426,6 +440,20 @@ static void snn_additions_party(InProcHub *hub, size_t p) {
     if (p != 2)
         for (size_t i = 0; i < n; i++) CHECK(Rr[i] == (A[i] < 0 ? 0 : A[i]));
     if (p != 2) printf("KAT snn_relu_fused_2001_R %zu %016lX\n", p, (unsigned long)fnv(R2.data(), n));
+    {
+        SecurennEngine e(&msgr, p);
+        for (size_t m : {(size_t)0, (size_t)1, (size_t)63, (size_t)65, (size_t)130}) {
+            vector<int64_t> Y(m), Yj, Rj, Yr;
+            for (auto &y : Y) y = g.pop_int64() / 2;
+            e.share(Y, Yj);
+            e.relu(Yj, Rj);
+            e.reveal(Rj, Yr);
+            if (p != 2) {
+                CHECK(Yr.size() == m);
+                for (size_t i = 0; i < m; i++) CHECK(Yr[i] == (Y[i] < 0 ? 0 : Y[i]));
+            }
+        }
+    }
     {
         SecurennEngine e(&msgr, p);
         PRgenerator h(34 + p, 0);
