@@ -9,8 +9,9 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
-#include <condition_variable>
 #include <atomic>
+#include <chrono>
+#include <condition_variable>
 #include <deque>
 #include <map>
 #include <mutex>
@@ -25,6 +26,7 @@ namespace {
 
 struct Table {
     std::mutex mu; // walk and upload of THIS stream; streams are extended independently of one another
+    std::atomic<int> waiters{0}; // engine calls waiting for mu: the background thread stays away while there are any
     std::vector<PrgCk> host; // host[e] = state before stream word PRG_CK*e
     PrgCk *dev = nullptr;
     u64 dev_cap = 0, dev_count = 0;
@@ -37,6 +39,35 @@ struct Table {
     u64 last_need = 0;    // the previous request, for the rate at which the stream is consumed
     u64 loaded_from_disk = 0, saved_to_disk = 0;
     u64 disk_seen_size = 0, disk_seen_mtime = 0; // the cache file as ckpt_load last saw it
+};
+// An engine call's hold on a table.
+struct CallerLock {
+    Table &T;
+    explicit CallerLock(Table &t) : T(t) {
+        T.waiters.fetch_add(1);
+        T.mu.lock();
+        T.waiters.fetch_sub(1);
+    }
+    ~CallerLock() { T.mu.unlock(); }
+    CallerLock(const CallerLock &) = delete;
+    CallerLock &operator=(const CallerLock &) = delete;
+};
+// The background thread's hold: short (one slice of a walk appended, one chunk of an upload or of a file written), and
+// given up at once when an engine call has asked for the table in the meantime -- a plain mutex would let the thread
+// that releases and re-takes it in a loop win against a waiting caller again and again.
+struct WalkerLock {
+    Table &T;
+    explicit WalkerLock(Table &t) : T(t) {
+        for (;;) {
+            while (T.waiters.load() > 0) std::this_thread::sleep_for(std::chrono::microseconds(50));
+            T.mu.lock();
+            if (T.waiters.load() == 0) return;
+            T.mu.unlock();
+        }
+    }
+    ~WalkerLock() { T.mu.unlock(); }
+    WalkerLock(const WalkerLock &) = delete;
+    WalkerLock &operator=(const WalkerLock &) = delete;
 };
 struct Key {
     int device;
@@ -52,6 +83,8 @@ struct Registry {
     std::mutex mu; // guards the map itself (its nodes never move)
     std::map<Key, Table> tables;
     std::map<int, int> live_contexts; // per device
+    std::mutex smu; // guards upload_streams only; nothing else is taken while it is held
+    std::map<int, hipStream_t> upload_streams; // per device, never destroyed
     // background walker: one thread, jobs = (table, device)
     std::mutex qmu;
     std::condition_variable qcv;
@@ -100,19 +133,29 @@ std::string ckpt_path(u64 seed, u64 lcg) {
     snprintf(name, sizeof name, "/prg_%016llx_%016llx.ckpt", (unsigned long long)seed, (unsigned long long)lcg);
     return dir + name;
 }
-// four interleaved multiply-xor lanes over the 64-bit words of the body (a serial chain would cost as much as the walk)
-u64 ckpt_checksum(const PrgCk *v, u64 count) {
-    const u64 *w = (const u64 *)v;
-    const u64 nw = count * (sizeof(PrgCk) / 8);
+// four interleaved multiply-xor lanes over the 64-bit words of the body (a serial chain would cost as much as the walk);
+// fed in pieces, every piece but the last a multiple of four checkpoints
+struct CkptSum {
     u64 h[4] = {0x243F6A8885A308D3ull, 0x13198A2E03707344ull, 0xA4093822299F31D0ull, 0x082EFA98EC4E6C89ull};
-    u64 i = 0;
-    for (; i + 4 <= nw; i += 4)
-        for (int k = 0; k < 4; k++) {
-            h[k] = (h[k] ^ w[i + k]) * 0x9E3779B97F4A7C15ull;
-            h[k] ^= h[k] >> 29;
-        }
-    for (; i < nw; i++) h[0] = ((h[0] ^ w[i]) * 0x9E3779B97F4A7C15ull) ^ (h[0] >> 31);
-    return (h[0] * 3 + h[1] * 5 + h[2] * 7 + h[3] * 11) ^ nw;
+    u64 nw = 0;
+    void add(const PrgCk *v, u64 count) {
+        const u64 *w = (const u64 *)v;
+        const u64 n = count * (sizeof(PrgCk) / 8);
+        u64 i = 0;
+        for (; i + 4 <= n; i += 4)
+            for (int k = 0; k < 4; k++) {
+                h[k] = (h[k] ^ w[i + k]) * 0x9E3779B97F4A7C15ull;
+                h[k] ^= h[k] >> 29;
+            }
+        for (; i < n; i++) h[0] = ((h[0] ^ w[i]) * 0x9E3779B97F4A7C15ull) ^ (h[0] >> 31);
+        nw += n;
+    }
+    u64 value() const { return (h[0] * 3 + h[1] * 5 + h[2] * 7 + h[3] * 11) ^ nw; }
+};
+u64 ckpt_checksum(const PrgCk *v, u64 count) {
+    CkptSum s;
+    s.add(v, count);
+    return s.value();
 }
 void ckpt_load(Table &T, u64 seed, u64 lcg) {
     const std::string path = ckpt_path(seed, lcg);
@@ -150,23 +193,59 @@ void ckpt_load(Table &T, u64 seed, u64 lcg) {
     }
     fclose(f);
 }
-void ckpt_save(Table &T, u64 seed, u64 lcg) {
+const u64 CKPT_CHUNK = 262144; // checkpoints (6 MB) the background thread handles per hold of a table's lock
+// Writes the table to the cache.  background = false: the caller holds T.mu throughout.  background = true (the
+// background thread, T.mu not held): the lock is taken for one chunk at a time, so an engine call that needs the table
+// waits for a few megabytes at most; the entries being written never change (a table only grows), and `stopping`
+// abandons the write.
+template <class Stop> void ckpt_save(Table &T, u64 seed, u64 lcg, bool background, Stop stopping) {
     const std::string path = ckpt_path(seed, lcg);
-    if (path.empty() || T.host.size() <= T.saved_to_disk + T.saved_to_disk / 4 + 4096) return;
+    if (path.empty()) return;
+    auto locked = [&](auto &&f) {
+        if (background) {
+            WalkerLock g(T);
+            f();
+        } else {
+            f();
+        }
+    };
+    u64 count = 0;
+    locked([&] {
+        count = T.host.size();
+        if (count <= T.saved_to_disk + T.saved_to_disk / 4 + 4096) count = 0;
+    });
     // in the implicit directory (nobody asked for a cache) tables beyond 256 MiB stay in memory only: with the sparse
     // marks a long stream is walked about as fast as such a file is read, and a home directory is no place for gigabytes
-    if (!getenv("MPCX_CKPT_CACHE") && T.host.size() * sizeof(PrgCk) > (256ull << 20)) return;
+    if (!count || (!getenv("MPCX_CKPT_CACHE") && count * sizeof(PrgCk) > (256ull << 20))) return;
     char tmp[32];
     snprintf(tmp, sizeof tmp, ".tmp.%ld", (long)getpid());
     const std::string tpath = path + tmp;
     FILE *f = fopen(tpath.c_str(), "wb");
     if (!f) return;
-    const u64 hdr[5] = {CKPT_MAGIC, seed, lcg, (u64)T.host.size(), ckpt_checksum(T.host.data(), T.host.size())};
-    const bool ok = fwrite(hdr, 8, 5, f) == 5 && fwrite(T.host.data(), sizeof(PrgCk), T.host.size(), f) == T.host.size();
+    u64 hdr[5] = {0, 0, 0, 0, 0}; // the real header goes in when the body is complete
+    bool ok = fwrite(hdr, 8, 5, f) == 5;
+    CkptSum sum;
+    for (u64 done = 0; ok && done < count;) {
+        const u64 n = count - done < CKPT_CHUNK ? count - done : CKPT_CHUNK;
+        locked([&] {
+            const PrgCk *src = T.host.data() + done;
+            ok = fwrite(src, sizeof(PrgCk), n, f) == n;
+            sum.add(src, n);
+        });
+        done += n;
+        if (background && stopping()) ok = false;
+    }
+    hdr[0] = CKPT_MAGIC, hdr[1] = seed, hdr[2] = lcg, hdr[3] = count, hdr[4] = sum.value();
+    ok = ok && fseek(f, 0, SEEK_SET) == 0 && fwrite(hdr, 8, 5, f) == 5;
     if (fclose(f) == 0 && ok && rename(tpath.c_str(), path.c_str()) == 0)
-        T.saved_to_disk = T.host.size();
+        locked([&] {
+            if (T.saved_to_disk < count) T.saved_to_disk = count;
+        });
     else
         remove(tpath.c_str());
+}
+void ckpt_save(Table &T, u64 seed, u64 lcg) { // T.mu held
+    ckpt_save(T, seed, lcg, false, [] { return false; });
 }
 
 // ---- sparse marks: the state of a stream every MARK_STRIDE words, for the streams whose keys are compile-time
@@ -291,34 +370,115 @@ void walk_to(Table &T, u64 want, u64 seed = 0, u64 lcg = 0, bool keyed = false) 
     if (keyed && want - T.host.size() >= (1u << 17)) (void)walk_with_marks(T, seed, lcg, want); // 2^23 words and more
     walk_serial(T, want);
 }
+// Table uploads run on a stream of their own that does not synchronise with the null stream: an engine that works on
+// the null stream (torch's default) has kernels queued there, and a plain hipMemcpy would wait for all of them.
+hipError_t upload_stream(int device, hipStream_t *out) { // the device current
+    Registry &R = reg();
+    std::lock_guard<std::mutex> g(R.smu);
+    auto it = R.upload_streams.find(device);
+    if (it == R.upload_streams.end()) {
+        hipStream_t s = nullptr;
+        hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+        if (e != hipSuccess) return e;
+        it = R.upload_streams.emplace(device, s).first;
+    }
+    *out = it->second;
+    return hipSuccess;
+}
+hipError_t upload_copy(PrgCk *dst, const PrgCk *src, u64 count, hipStream_t s) {
+    hipError_t e = hipMemcpyAsync(dst, src, count * sizeof(PrgCk), hipMemcpyHostToDevice, s);
+    return e == hipSuccess ? hipStreamSynchronize(s) : e; // complete before anybody is told that the entries exist
+}
+// room of a device copy for `have` checkpoints: the first copy is sized to the request; a table that grows again is
+// a pop stream on the move and gets half as much spare room again, so that the superseded copies stay a geometric series
+u64 upload_capacity(const Table &T, u64 have) { return have + ((T.dev && have / 2 > 4096) ? have / 2 : 4096); }
 // mirrors T.host on the device (T.mu held, the device current); returns a hipError_t
-hipError_t upload(Table &T) {
+hipError_t upload(Table &T, int device) {
     const u64 have = T.host.size();
     if (T.dev_count >= have) return hipSuccess;
+    hipStream_t s;
+    hipError_t e = upload_stream(device, &s);
+    if (e != hipSuccess) return e;
     if (T.dev_cap < have) {
-        // the first copy is sized to the request; a table that grows again is a pop stream on the move and gets
-        // half as much spare room again, so that the superseded copies stay a geometric series
-        const u64 room = (T.dev && have / 2 > 4096) ? have / 2 : 4096;
-        const u64 cap = have + room;
+        const u64 cap = upload_capacity(T, have);
         PrgCk *nd = nullptr;
-        hipError_t e = hipMalloc((void **)&nd, cap * sizeof(PrgCk));
+        e = hipMalloc((void **)&nd, cap * sizeof(PrgCk));
         if (e != hipSuccess) return e;
         if (T.dev) T.retired.push_back(T.dev);
         T.dev = nd;
         T.dev_cap = cap;
         T.dev_count = 0;
     }
-    hipError_t e = hipMemcpy(T.dev + T.dev_count, T.host.data() + T.dev_count, (have - T.dev_count) * sizeof(PrgCk),
-                             hipMemcpyHostToDevice);
+    e = upload_copy(T.dev + T.dev_count, T.host.data() + T.dev_count, have - T.dev_count, s);
     if (e == hipSuccess) T.dev_count = have;
     return e;
+}
+// The same from the background thread (T.mu NOT held, the device current): the lock is taken for one chunk at a time,
+// and a larger device copy is filled completely before the table points at it, so an engine call never waits for more
+// than a few megabytes and never sees a copy that is half there.  false = given up (error, or the process is ending).
+template <class Stop> bool upload_background(Table &T, int device, Stop stopping) {
+    hipStream_t s;
+    if (upload_stream(device, &s) != hipSuccess) return false;
+    PrgCk *fresh = nullptr; // a larger copy in the making
+    u64 fresh_cap = 0, filled = 0;
+    for (;;) {
+        if (stopping()) break;
+        u64 want_cap = 0;
+        {
+            WalkerLock g(T);
+            const u64 have = T.host.size();
+            if (T.dev_count >= have) { // the live copy is complete (an engine call may have seen to it)
+                if (fresh) (void)hipFree(fresh);
+                return true;
+            }
+            if (fresh && T.dev_cap >= have && T.dev_count >= filled) {
+                // an engine call has installed a copy with room of its own meanwhile: this one is superfluous
+                (void)hipFree(fresh);
+                fresh = nullptr;
+            }
+            if (!fresh && T.dev_cap >= have) { // room in the live copy: append a chunk
+                const u64 n = have - T.dev_count < CKPT_CHUNK ? have - T.dev_count : CKPT_CHUNK;
+                if (upload_copy(T.dev + T.dev_count, T.host.data() + T.dev_count, n, s) != hipSuccess) return false;
+                T.dev_count += n;
+                continue;
+            }
+            if (fresh) {
+                const u64 upto = have < fresh_cap ? have : fresh_cap;
+                const u64 n = upto - filled < CKPT_CHUNK ? upto - filled : CKPT_CHUNK;
+                if (n && upload_copy(fresh + filled, T.host.data() + filled, n, s) != hipSuccess) break;
+                filled += n;
+                if (filled == upto) { // caught up with the table: the new copy takes over
+                    if (filled > T.dev_count) {
+                        if (T.dev) T.retired.push_back(T.dev);
+                        T.dev = fresh;
+                        T.dev_cap = fresh_cap;
+                        T.dev_count = filled;
+                    } else {
+                        (void)hipFree(fresh);
+                    }
+                    fresh = nullptr;
+                }
+                continue;
+            }
+            want_cap = upload_capacity(T, have);
+        }
+        // a larger copy is needed: allocated without the lock
+        if (hipMalloc((void **)&fresh, want_cap * sizeof(PrgCk)) != hipSuccess) return false;
+        fresh_cap = want_cap;
+        filled = 0;
+    }
+    if (fresh) (void)hipFree(fresh);
+    return false;
 }
 
 // The background walker: a pop stream is consumed a little further by every engine call, and its serial walk
 // (~1 ns per word on one core) would otherwise sit in front of every call.  After a request has been served, the
-// walker carries the table on to bg_target in slices, taking the table's lock only for a slice at a time.
+// walker carries the table on to bg_target: it walks a slice from the table's last state WITHOUT the table's lock and
+// appends it under the lock (unless an engine call has extended the table itself in the meantime), then mirrors the table
+// on the device and writes it to the cache, a chunk per hold of the lock.
 void walker_main() {
     Registry &R = reg();
+    std::vector<PrgCk> slice;
     for (;;) {
         std::pair<Table *, Key> job;
         {
@@ -332,35 +492,63 @@ void walker_main() {
             R.walker_busy = true;
         }
         Table &T = *job.first;
-        // a job that is dropped (the device cannot be made current, or the process is ending) hands the table back:
-        // with bg_target left above the table's size, walk_ahead would take the job for still running and never
-        // queue another one
+        const Key key = job.second;
+        auto stopping = [&] {
+            std::lock_guard<std::mutex> lk(R.qmu);
+            return R.stop;
+        };
+        // a job that is dropped (the device cannot be made current, an upload fails, or the process is ending) hands
+        // the table back: with bg_target left above the table's size, walk_ahead would take the job for still running
+        // and never queue another one
         auto drop = [&] {
-            std::lock_guard<std::mutex> g(T.mu);
+            WalkerLock g(T);
             T.bg_target = T.host.size();
             T.job_queued = false;
         };
-        if (hipSetDevice(job.second.device) != hipSuccess) {
+        if (hipSetDevice(key.device) != hipSuccess) {
             drop();
             continue;
         }
-        for (;;) {
-            {
-                std::lock_guard<std::mutex> lk(R.qmu);
-                if (R.stop) {
-                    drop();
+        for (bool finished = false; !finished;) {
+            bool alive = true;
+            for (;;) { // the walk
+                if (stopping()) {
+                    alive = false;
                     break;
                 }
+                PrgCk c;
+                u64 size0, target;
+                {
+                    WalkerLock g(T);
+                    size0 = T.host.size();
+                    target = T.bg_target;
+                    c = T.host.back();
+                }
+                if (size0 >= target) break;
+                const u64 n = target - size0 < 32768 ? target - size0 : 32768; // ~2 M words, a few milliseconds
+                slice.resize(n);
+                for (u64 e = 0; e < n; e++) {
+                    for (u64 i = 0; i < PRG_CK; i++) prv_step(c.seed, c.lcg, c.hash);
+                    slice[e] = c;
+                }
+                WalkerLock g(T);
+                if (T.host.size() != size0) continue; // an engine call walked on from the same state: its entries stand
+                if (T.host.capacity() < size0 + n) { // rarely: the whole table moves (geometric growth, or to the target)
+                    const u64 geo = T.host.capacity() + T.host.capacity() / 2;
+                    T.host.reserve(target > geo ? target : geo);
+                }
+                T.host.insert(T.host.end(), slice.begin(), slice.end());
             }
-            std::lock_guard<std::mutex> g(T.mu);
-            if (T.host.size() >= T.bg_target) {
-                (void)upload(T);
-                ckpt_save(T, job.second.seed, job.second.lcg);
-                T.job_queued = false;
+            if (!alive || !upload_background(T, key.device, stopping)) {
+                drop();
                 break;
             }
-            const u64 slice = T.host.size() + 32768; // ~2 M words, a few milliseconds
-            walk_to(T, slice < T.bg_target ? slice : T.bg_target);
+            ckpt_save(T, key.seed, key.lcg, true, stopping);
+            WalkerLock g(T);
+            if (T.host.size() >= T.bg_target) { // no further request came in meanwhile
+                T.job_queued = false;
+                finished = true;
+            }
         }
     }
 }
@@ -492,7 +680,7 @@ __global__ __launch_bounds__(256) void prg_mod67_listed_kernel(const PrgCk *__re
 // the node may be waiting for the file); otherwise the background thread writes it, off the caller's path
 static int prg_table(mpcx_ctx *ctx, u64 seed, u64 lcg, u64 t_end, const PrgCk **dev, bool save_now) {
     Table &T = table_of(ctx->device, seed, lcg);
-    std::lock_guard<std::mutex> g(T.mu);
+    CallerLock g(T);
     if (T.host.empty()) {
         u64 s = seed, l = lcg, h = 0;
         for (int i = 0; i < 5; i++) prv_step(s, l, h); // utils/PRgenerator.cpp:23-26
@@ -514,18 +702,24 @@ static int prg_table(mpcx_ctx *ctx, u64 seed, u64 lcg, u64 t_end, const PrgCk **
     }
     if (save_now) ckpt_save(T, seed, lcg); // also what the background thread walked since the last write
     // The background walker keeps the table ahead of a stream that is being consumed: four times the step from the
-    // previous request, within 16 Mi .. 256 Mi words, started when less than half of that is left.
+    // previous request, within 16 Mi .. 256 Mi words, started when less than half of that is left.  Only a request
+    // beyond everything asked before counts as consumption: the first one says nothing about a rate (and a table built
+    // by mpcx_prg_ckpt_build has been given its length), and a stream that is read again from the start -- fresh engines
+    // with the same keys -- has its table already.
     {
-        const u64 step = need > T.last_need ? need - T.last_need : 0;
+        const bool advancing = T.last_need != 0 && need > T.last_need && !save_now;
+        const u64 step = advancing ? need - T.last_need : 0;
         if (need > T.last_need) T.last_need = need;
-        u64 more = 4 * step;
-        const u64 lo = (16ull << 20) / PRG_CK, hi = (256ull << 20) / PRG_CK;
-        more = more < lo ? lo : more > hi ? hi : more;
-        if (T.host.size() < need + more / 2) walk_ahead(T, Key{ctx->device, seed, lcg}, need + more);
+        if (advancing) {
+            u64 more = 4 * step;
+            const u64 lo = (16ull << 20) / PRG_CK, hi = (256ull << 20) / PRG_CK;
+            more = more < lo ? lo : more > hi ? hi : more;
+            if (T.host.size() < need + more / 2) walk_ahead(T, Key{ctx->device, seed, lcg}, need + more);
+        }
     }
     if (T.dev_count < need) {
         MPCX_HIP(hipSetDevice(ctx->device));
-        MPCX_HIP(upload(T));
+        MPCX_HIP(upload(T, ctx->device));
     }
     *dev = T.dev;
     return 0;
@@ -546,7 +740,7 @@ void prg_tables_context_closed(int device) {
     if (--R.live_contexts[device] > 0) return;
     for (auto &kv : R.tables)
         if (kv.first.device == device) {
-            std::lock_guard<std::mutex> t(kv.second.mu);
+            CallerLock t(kv.second);
             for (PrgCk *p : kv.second.retired) (void)hipFree(p);
             kv.second.retired.clear();
         }
@@ -720,7 +914,7 @@ int mpcx_prg_state_at_pop(mpcx_ctx *ctx, uint64_t seed, uint64_t lcg, uint64_t p
     PrgCk c;
     {
         Table &T = table_of(ctx->device, seed, lcg);
-        std::lock_guard<std::mutex> g(T.mu);
+        CallerLock g(T);
         c = T.host[t / PRG_CK];
     }
     for (u64 i = (t / PRG_CK) * PRG_CK; i < t; i++) prv_step(c.seed, c.lcg, c.hash);

@@ -317,6 +317,52 @@ def test_sparse_marks_parallel_walk_is_exact_and_not_trusted(tmp_path):
     assert secs(with_marks) < secs(serial), (secs(with_marks), secs(serial))
 
 
+def test_stream_consumed_while_the_background_thread_extends_it(tmp_path):
+    """A pop stream read further and further (what an engine does): from the second request on the library's background
+    thread walks ahead of the reader, appends to the table, mirrors it on the device (in place, and into larger copies
+    when it outgrows one) and writes it to the cache directory, holding the table's lock for a slice at a time.  Every
+    request returns the oracle's words whatever the thread is doing at that moment, and the file it leaves behind is one
+    the next process accepts."""
+    import sys
+    from oracle_lib import prg_pops
+    step, rounds, count = 5_000_000, 14, 512
+    prog = ("import sys, time, glob, numpy as np; sys.path.insert(0, %r); from mpc_amd import Context; c = Context(0); "
+            "d = c.empty(np.int64, %d)\n"
+            "for i in range(%d):\n"
+            "    c.call('prg_fill_pop', 0x79, 0, i * %d, %d, d); c.sync()\n"
+            "    print('WORDS', i, ' '.join('%%x' %% (int(v) & (2**64 - 1)) for v in d.to_host()))\n"
+            "    time.sleep(0.02 * (i %% 3))\n"
+            "t0 = time.time()\n"
+            "while time.time() - t0 < 20 and not glob.glob(%r + '/prg_*.ckpt'): time.sleep(0.05)\n"
+            "c.close()\n" % (ROOT, count, rounds, step, count, str(tmp_path)))
+    env = dict(os.environ, MPCX_CKPT_CACHE=str(tmp_path))
+    env.pop("MPCX_PRG_WALK_AHEAD", None)
+    r = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l.split() for l in r.stdout.splitlines() if l.startswith("WORDS")]
+    assert len(lines) == rounds
+    for l in lines:
+        i = int(l[1])
+        want = ["%x" % (int(v) & (2 ** 64 - 1)) for v in prg_pops(0x79, i * step, count)]
+        assert l[2:] == want, f"request {i} differs from the oracle"
+    files = list(tmp_path.glob("prg_*.ckpt"))
+    assert len(files) == 1 and not list(tmp_path.glob("*.tmp.*"))
+    size = files[0].stat().st_size
+    assert size >= 40 + 24 * (2 * step // 64)  # written by the background thread, after it walked ahead at least once
+    # the next process (background thread off) accepts the file: it reads words near its end without rewriting it
+    last = (size - 40) // 24 * 64 - 320000 - 8192  # pops start at stream word 320000 (utils/PRgenerator.hpp:6)
+    prog2 = ("import sys, numpy as np; sys.path.insert(0, %r); from mpc_amd import Context; c = Context(0); "
+             "d = c.empty(np.int64, %d); c.call('prg_fill_pop', 0x79, 0, %d, %d, d); c.sync(); "
+             "print('WORDS', ' '.join('%%x' %% (int(v) & (2**64 - 1)) for v in d.to_host()))" % (ROOT, count, last - count, count))
+    mtime = files[0].stat().st_mtime_ns
+    r2 = subprocess.run([sys.executable, "-c", prog2], capture_output=True, text=True, timeout=300,
+                        env=dict(env, MPCX_PRG_WALK_AHEAD="0"))
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    want = "WORDS " + " ".join("%x" % (int(v) & (2 ** 64 - 1)) for v in prg_pops(0x79, last - count, count))
+    assert r2.stdout.strip() == want
+    assert files[0].stat().st_mtime_ns == mtime and files[0].stat().st_size == size
+
+
 @pytest.mark.parametrize("nbytes", [1, 4095, (4 << 20) - 1, 4 << 20, (4 << 20) + 1, (12 << 20) - 3, (37 << 20) + 5])
 def test_host_device_copies_round_trip(nbytes):
     """mpcx_h2d / mpcx_d2h (plain below 4 MiB, pipelined through the pinned staging buffers above, ragged last chunks)
