@@ -353,6 +353,22 @@ void ABY3Engine::reveal_bits(const array<VecI64, 2> &Xj, VecI64 &X_plain) {
     out.down(X_plain.data(), n);
 }
 
+// A row-major message of rows x cols words into a (column-major) matrix.  Large ones go through the device -- upload,
+// turn, download: three streaming copies -- because a transposing pass over host memory is several times slower than a
+// streaming one; small ones are turned on the host.
+static const size_t kDeviceTransposeWords = (size_t)1 << 18;
+void ABY3Engine::wire_to_matrix(const string &wire, size_t rows, size_t cols, MatrixXl &M) {
+    M.resize(rows, cols);
+    if (rows * cols < kDeviceTransposeWords) {
+        string2matrix(wire, M);
+        return;
+    }
+    Dev<int64_t> rm(gpu, rows * cols), cm(gpu, rows * cols);
+    upload_string(rm, wire);
+    GPU_OK(gpu, mpcx_relayout(gpu, rm, cm, rows, cols, 0, 1));
+    cm.down(M.data(), rows * cols);
+}
+
 // ---- products
 void ABY3Engine::matrix_mul(const array<MatrixXl, 2> &Xj, const array<MatrixXl, 2> &Yj, array<MatrixXl, 2> &Zj) {
     const Peers pe(party_id);
@@ -361,6 +377,7 @@ void ABY3Engine::matrix_mul(const array<MatrixXl, 2> &Xj, const array<MatrixXl, 
     assert(Xj[1].rows() == rows && Xj[1].cols() == lens);
     assert(Yj[1].rows() == lens && Yj[1].cols() == cols);
     message_send[pe.next].clear();
+    bool z0_done = false; // Zj[0] already written from the device copy of the product
     if (group && rows && lens && cols) {
         // row blocks over the group's GPUs, each written into its place of the outgoing message; a pinned second operand
         // is on every member already
@@ -407,6 +424,15 @@ void ABY3Engine::matrix_mul(const array<MatrixXl, 2> &Xj, const array<MatrixXl, 
         }
         mpcgpu::Span s3("matrix_mul: download");
         z.to_string(message_send[pe.prev]);
+        if (rows * cols >= kDeviceTransposeWords) {
+            // the caller's copy of the share, column-major as Eigen stores it: turned on the device and copied straight
+            // into the matrix (a transposing pass over host memory costs several such copies)
+            Dev<int64_t> zc(gpu, rows * cols);
+            GPU_OK(gpu, mpcx_relayout(gpu, z, zc, rows, cols, 0, 1));
+            Zj[0].resize(rows, cols);
+            zc.down(Zj[0].data(), rows * cols);
+            z0_done = true;
+        }
     }
     {
         mpcgpu::Span s4("matrix_mul: advance");
@@ -418,10 +444,9 @@ void ABY3Engine::matrix_mul(const array<MatrixXl, 2> &Xj, const array<MatrixXl, 
         messenger->send_and_recv(message_send, message_recv);
     }
     mpcgpu::Span s6("matrix_mul: to matrices");
-    Zj[0].resize(rows, cols);
-    Zj[1].resize(rows, cols);
-    string2matrix(message_send[pe.prev], Zj[0]);
-    string2matrix(message_recv[pe.next], Zj[1]);
+    MSG_CHECK(message_recv[pe.next].size() == rows * cols * sizeof(int64_t));
+    if (!z0_done) wire_to_matrix(message_send[pe.prev], rows, cols, Zj[0]);
+    wire_to_matrix(message_recv[pe.next], rows, cols, Zj[1]);
 #if defined MYDEBUG // the product of the revealed operands (ABY3Engine.cpp:202-209)
     MatrixXl xd, yd, zd;
     reveal_matrix(Xj, xd);

@@ -95,4 +95,6 @@ class ABY3Engine {
     struct Pinned;
     std::vector<Pinned *> pinned;
     Pinned *find_pinned(const MatPair &M) const;
+    // a row-major message of rows x cols words into a matrix (large ones are turned on the device)
+    void wire_to_matrix(const string &wire, size_t rows, size_t cols, MatrixXl &M);
 };
