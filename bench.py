@@ -542,6 +542,11 @@ def merge_bitwise(per_rank):
         out[f"pc_party_{label}_hbm_frac"] = out[f"pc_party_{label}_GBps_per_gpu"] / HBM_PEAK_GBS
     out["pc_helper_GBps_per_gpu"] = 257.0 * out["pc_helper_elems_per_s"] / g / 1e9
     out["pc_helper_hbm_frac"] = out["pc_helper_GBps_per_gpu"] / HBM_PEAK_GBS
+    # SecureNN msb: 648 B/elem for each of the roles of parties 0 / 1 (8 in + 8 out + 288 sent + 344 received); the
+    # helper's bytes are not counted, so the fraction is a lower bound for the three roles this GPU plays
+    for label in ("cold", "warm"):
+        out[f"snn_msb_{label}_GBps_per_gpu"] = 2 * 648.0 * out[f"snn_msb_{label}_elems_per_s"] / g / 1e9
+        out[f"snn_msb_{label}_hbm_frac"] = out[f"snn_msb_{label}_GBps_per_gpu"] / HBM_PEAK_GBS
     out["aby3_relu_GBps_per_gpu"] = 3 * 380.0 * out["aby3_relu_elems_per_s"] / g / 1e9
     out["aby3_relu_hbm_frac"] = out["aby3_relu_GBps_per_gpu"] / HBM_PEAK_GBS
     out["ranks"] = g

@@ -6,15 +6,18 @@
 // 256-thread workgroup therefore owns 256 consecutive segments; every 16 steps the lanes
 // park their words in LDS and the workgroup writes them out as whole 128-byte lines.
 #include <dlfcn.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
 #include <atomic>
 #include <chrono>
+#include <cstring>
 #include <condition_variable>
 #include <deque>
 #include <map>
 #include <mutex>
+#include <new>
 #include <string>
 #include <thread>
 #include <vector>
@@ -24,10 +27,68 @@
 
 namespace {
 
+// The host copy of a checkpoint table: a contiguous array that grows by remapping its pages (mremap) instead of
+// copying them.  A table reaches gigabytes (0.375 bytes per stream word), it grows while engine calls wait for its lock,
+// and a std::vector would copy all of it whenever it outgrows its capacity -- hundreds of milliseconds in front of
+// whichever call comes next.  Fresh pages are zero; entries are plain data.
+class CkVec {
+    PrgCk *p_ = nullptr;
+    u64 n_ = 0, cap_ = 0;
+    static u64 bytes_for(u64 cap) { return (cap * sizeof(PrgCk) + (2u << 20) - 1) & ~(u64)((2u << 20) - 1); }
+
+  public:
+    CkVec() = default;
+    CkVec(const CkVec &) = delete;
+    CkVec &operator=(const CkVec &) = delete;
+    ~CkVec() {
+        if (p_) munmap(p_, bytes_for(cap_));
+    }
+    u64 size() const { return n_; }
+    u64 capacity() const { return cap_; }
+    bool empty() const { return n_ == 0; }
+    PrgCk *data() { return p_; }
+    const PrgCk *data() const { return p_; }
+    PrgCk &operator[](u64 i) { return p_[i]; }
+    const PrgCk &operator[](u64 i) const { return p_[i]; }
+    const PrgCk &back() const { return p_[n_ - 1]; }
+    void reserve(u64 cap) { // throws std::bad_alloc like the container it replaces
+        if (cap <= cap_) return;
+        const u64 nb = bytes_for(cap);
+        void *q = p_ ? mremap(p_, bytes_for(cap_), nb, MREMAP_MAYMOVE)
+                     : mmap(nullptr, nb, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (q == MAP_FAILED) throw std::bad_alloc();
+        p_ = (PrgCk *)q;
+        cap_ = nb / sizeof(PrgCk);
+    }
+    void grow_for(u64 want) { // room for `want` entries, at least half as much again as there is
+        if (want <= cap_) return;
+        const u64 geo = cap_ + cap_ / 2;
+        reserve(want > geo ? want : geo);
+    }
+    void resize(u64 n) { // new entries are unspecified (zero when the pages are fresh)
+        grow_for(n);
+        n_ = n;
+    }
+    void push_back(const PrgCk &c) {
+        grow_for(n_ + 1);
+        p_[n_++] = c;
+    }
+    void append(const PrgCk *src, u64 count) {
+        grow_for(n_ + count);
+        memcpy(p_ + n_, src, count * sizeof(PrgCk));
+        n_ += count;
+    }
+    void swap(CkVec &o) {
+        std::swap(p_, o.p_);
+        std::swap(n_, o.n_);
+        std::swap(cap_, o.cap_);
+    }
+};
+
 struct Table {
     std::mutex mu; // walk and upload of THIS stream; streams are extended independently of one another
     std::atomic<int> waiters{0}; // engine calls waiting for mu: the background thread stays away while there are any
-    std::vector<PrgCk> host; // host[e] = state before stream word PRG_CK*e
+    CkVec host; // host[e] = state before stream word PRG_CK*e
     PrgCk *dev = nullptr;
     u64 dev_cap = 0, dev_count = 0;
     // Older, smaller device copies.  A table is shared by every context of the device, so a kernel of another
@@ -174,7 +235,8 @@ void ckpt_load(Table &T, u64 seed, u64 lcg) {
                         (u64)st.st_size == CKPT_HDR_BYTES + hdr[3] * sizeof(PrgCk);
     if (hdr_ok) {
         try {
-            std::vector<PrgCk> v(hdr[3]);
+            CkVec v;
+            v.resize(hdr[3]);
             // a file that another process is replacing is complete or absent (rename); a short read is ignored
             bool ok = fread(v.data(), sizeof(PrgCk), hdr[3], f) == hdr[3] && v[0].seed == T.host[0].seed &&
                       v[0].lcg == T.host[0].lcg && v[0].hash == T.host[0].hash && ckpt_checksum(v.data(), hdr[3]) == hdr[4];
@@ -363,10 +425,7 @@ bool walk_with_marks(Table &T, u64 seed, u64 lcg, u64 want) {
 // extends T.host to at least `want` checkpoints (T.mu held)
 void walk_to(Table &T, u64 want, u64 seed = 0, u64 lcg = 0, bool keyed = false) {
     if (T.host.size() >= want) return;
-    if (want > T.host.capacity()) { // grow the host copy geometrically (reserve alone would allocate exactly)
-        const u64 geo = T.host.capacity() + T.host.capacity() / 2;
-        T.host.reserve(want > geo ? want : geo);
-    }
+    T.host.grow_for(want);
     if (keyed && want - T.host.size() >= (1u << 17)) (void)walk_with_marks(T, seed, lcg, want); // 2^23 words and more
     walk_serial(T, want);
 }
@@ -389,9 +448,13 @@ hipError_t upload_copy(PrgCk *dst, const PrgCk *src, u64 count, hipStream_t s) {
     hipError_t e = hipMemcpyAsync(dst, src, count * sizeof(PrgCk), hipMemcpyHostToDevice, s);
     return e == hipSuccess ? hipStreamSynchronize(s) : e; // complete before anybody is told that the entries exist
 }
-// room of a device copy for `have` checkpoints: the first copy is sized to the request; a table that grows again is
-// a pop stream on the move and gets half as much spare room again, so that the superseded copies stay a geometric series
-u64 upload_capacity(const Table &T, u64 have) { return have + ((T.dev && have / 2 > 4096) ? have / 2 : 4096); }
+// room of a device copy for `have` checkpoints: the first copy gets a sixteenth more than the request (a table built to a
+// stated length is often read a few words further); a table that outgrows a copy is a pop stream on the move and gets
+// half as much spare room again, so that the superseded copies stay a geometric series
+u64 upload_capacity(const Table &T, u64 have) {
+    const u64 room = T.dev ? have / 2 : have / 16;
+    return have + (room > 4096 ? room : 4096);
+}
 // mirrors T.host on the device (T.mu held, the device current); returns a hipError_t
 hipError_t upload(Table &T, int device) {
     const u64 have = T.host.size();
@@ -533,11 +596,13 @@ void walker_main() {
                 }
                 WalkerLock g(T);
                 if (T.host.size() != size0) continue; // an engine call walked on from the same state: its entries stand
-                if (T.host.capacity() < size0 + n) { // rarely: the whole table moves (geometric growth, or to the target)
-                    const u64 geo = T.host.capacity() + T.host.capacity() / 2;
-                    T.host.reserve(target > geo ? target : geo);
+                try {
+                    T.host.grow_for(target); // pages are remapped, not copied
+                    T.host.append(slice.data(), n);
+                } catch (const std::bad_alloc &) { // no memory to walk ahead with: the calls walk what they need
+                    alive = false;
+                    break;
                 }
-                T.host.insert(T.host.end(), slice.begin(), slice.end());
             }
             if (!alive || !upload_background(T, key.device, stopping)) {
                 drop();
