@@ -245,6 +245,7 @@ const char *mpcx_last_error(mpcx_ctx *ctx) { return ctx ? ctx->err.c_str() : g_i
 
 int mpcx_set_stream(mpcx_ctx *ctx, void *hip_stream) {
     MPCX_REQUIRE(ctx, "mpcx_set_stream: the context is NULL (already shut down?)");
+    if (ctx->stream == (hipStream_t)hip_stream) return 0; // nothing changes (and the stream may be under capture)
     // work queued on the old stream may still use the workspace, cached slices and recycled blocks
     MPCX_HIP(hipStreamSynchronize(ctx->stream));
     if (ctx->own_stream && ctx->stream) MPCX_HIP(hipStreamDestroy(ctx->stream));
