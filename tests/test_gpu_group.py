@@ -363,6 +363,38 @@ def test_stream_consumed_while_the_background_thread_extends_it(tmp_path):
     assert files[0].stat().st_mtime_ns == mtime and files[0].stat().st_size == size
 
 
+def test_three_contexts_read_one_growing_stream_concurrently():
+    """Three host threads, each with a context of its own on the same GPU (the three parties of a single-process run),
+    read one generator stream at interleaved, advancing positions while the background thread extends its table: the
+    table's host copy moves when it grows, its device copy is replaced while kernels of the other contexts may still
+    read the old one, and every thread still gets the oracle's words."""
+    import threading
+    from mpc_amd import Context
+    from oracle_lib import prg_pops
+    seed, step, rounds, count = 0x7A, 1_700_000, 18, 384
+    results, errors = {}, []
+
+    def party(k):
+        try:
+            ctx = Context(0)
+            d = ctx.empty(np.int64, count)
+            for i in range(rounds):
+                first = (3 * i + k) * step
+                ctx.call("prg_fill_pop", seed, 0, first, count, d)
+                ctx.sync()
+                results[(k, i)] = d.to_host().copy()
+            ctx.close()
+        except Exception as ex:  # surfaced by the main thread
+            errors.append(f"thread {k}: {ex}")
+
+    th = [threading.Thread(target=party, args=(k,)) for k in range(3)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errors, errors
+    for (k, i), got in sorted(results.items()):
+        assert np.array_equal(got, prg_pops(seed, (3 * i + k) * step, count)), f"thread {k}, request {i}"
+
+
 @pytest.mark.parametrize("nbytes", [1, 4095, (4 << 20) - 1, 4 << 20, (4 << 20) + 1, (12 << 20) - 3, (37 << 20) + 5])
 def test_host_device_copies_round_trip(nbytes):
     """mpcx_h2d / mpcx_d2h (plain below 4 MiB, pipelined through the pinned staging buffers above, ragged last chunks)
