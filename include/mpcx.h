@@ -145,6 +145,22 @@ int mpcx_aby3_matmul_local_rows(mpcx_ctx *ctx, const int64_t *X0blk, const int64
                                 const int64_t *Y1, uint64_t rows, uint64_t l, uint64_t c, uint64_t row0,
                                 uint64_t seed_next, uint64_t pop_next, uint64_t seed_prev, uint64_t pop_prev,
                                 int64_t *Z0blk);
+/* The same product with a second operand that many calls use (weights): matrix_mul (:189-197) reads Y0 + Y1 and Y0
+ * afresh in every call; here the pair stays on the device where the caller keeps it (it must not change or go away
+ * before mpcx_aby3_operand_free) and, for shapes whose products run as 18 residue products, the residue planes of
+ * [Y0 + Y1 ; Y0] are made once by mpcx_aby3_operand_prepare (mpcx_aby3_operand_bytes tells how much device memory
+ * they take; 0 = none were made) and read by every mpcx_aby3_matmul_local_prepared.  X0 / X1: rows x l in layoutX
+ * (rows [row0, row0 + rows) of the whole operand, as in the row-block form), Z0: rows x c row-major.  Results are those
+ * of mpcx_aby3_matmul_local_rows, word for word. */
+typedef struct mpcx_aby3_operand mpcx_aby3_operand;
+int mpcx_aby3_operand_prepare(mpcx_ctx *ctx, const int64_t *Y0, const int64_t *Y1, uint64_t l, uint64_t c, int layout,
+                              mpcx_aby3_operand **out);
+int mpcx_aby3_operand_free(mpcx_ctx *ctx, mpcx_aby3_operand *op);
+uint64_t mpcx_aby3_operand_bytes(const mpcx_aby3_operand *op);
+uint64_t mpcx_aby3_operand_uses(const mpcx_aby3_operand *op); /* products so far that read the planes instead of splitting */
+int mpcx_aby3_matmul_local_prepared(mpcx_ctx *ctx, const int64_t *X0, const int64_t *X1, int layoutX,
+                                    const mpcx_aby3_operand *Y, uint64_t rows, uint64_t row0, uint64_t seed_next,
+                                    uint64_t pop_next, uint64_t seed_prev, uint64_t pop_prev, int64_t *Z0);
 /* vector_mul before the round (:220-227) */
 int mpcx_aby3_vecmul_local(mpcx_ctx *ctx, const int64_t *X0, const int64_t *X1, const int64_t *Y0, const int64_t *Y1,
                            uint64_t n, uint64_t seed_next, uint64_t pop_next, uint64_t seed_prev, uint64_t pop_prev,

@@ -304,13 +304,13 @@ int mpcx_aby3_share_bools_local(mpcx_ctx *ctx, const int8_t *X, uint64_t n, uint
 // Z0 = X0*(Y0+Y1) + X1*Y0 = [X0 | X1] * [Y0+Y1 ; Y0]  (ABY3Engine.cpp:189) as ONE K-concatenated ring
 // product, with the mask pop(next) - pop(prev) (:190-197) added in the product's epilogue.
 static int aby3_matmul_impl(mpcx_ctx *ctx, const i64 *X0, const i64 *X1, const i64 *Y0, const i64 *Y1, u64 rows, u64 l,
-                            u64 c, int layout, u64 first_word, u64 seed_next, u64 pop_next, u64 seed_prev, u64 pop_prev,
-                            i64 *Z0) {
+                            u64 c, int layoutX, int layoutY, u64 first_word, u64 seed_next, u64 pop_next, u64 seed_prev,
+                            u64 pop_prev, i64 *Z0, const RnsPreB *pre = nullptr) {
     // the mask words go straight into Z0 and the product is accumulated onto them
     MPCX_TRY(prg_fill_diff(ctx, seed_next, PRG_POP_T0 + pop_next + first_word, seed_prev, PRG_POP_T0 + pop_prev + first_word,
                            rows * c, nullptr, Z0));
     GemmPart parts[2] = {{X0, Y0, Y1}, {X1, Y0, nullptr}};
-    return ring_gemm_parts(ctx, parts, 2, rows, l, c, layout, layout, nullptr, nullptr, Z0, 0, 1);
+    return ring_gemm_parts(ctx, parts, 2, rows, l, c, layoutX, layoutY, nullptr, nullptr, Z0, 0, 1, pre);
 }
 
 int mpcx_aby3_matmul_local_rows(mpcx_ctx *ctx, const int64_t *X0, const int64_t *X1, const int64_t *Y0,
@@ -319,7 +319,7 @@ int mpcx_aby3_matmul_local_rows(mpcx_ctx *ctx, const int64_t *X0, const int64_t 
                                 int64_t *Z0) {
     MPCX_REQUIRE(X0 && X1 && Y0 && Y1 && Z0, "mpcx_aby3_matmul_local_rows: NULL operand");
     MPCX_REQUIRE(rows && l && c, "mpcx_aby3_matmul_local_rows: empty shape");
-    return aby3_matmul_impl(ctx, X0, X1, Y0, Y1, rows, l, c, 0, row0 * c, seed_next, pop_next, seed_prev, pop_prev, Z0);
+    return aby3_matmul_impl(ctx, X0, X1, Y0, Y1, rows, l, c, 0, 0, row0 * c, seed_next, pop_next, seed_prev, pop_prev, Z0);
 }
 
 int mpcx_aby3_matmul_local(mpcx_ctx *ctx, const int64_t *X0, const int64_t *X1, const int64_t *Y0, const int64_t *Y1,
@@ -328,7 +328,52 @@ int mpcx_aby3_matmul_local(mpcx_ctx *ctx, const int64_t *X0, const int64_t *X1, 
     MPCX_REQUIRE(X0 && X1 && Y0 && Y1 && Z0, "mpcx_aby3_matmul_local: NULL operand");
     MPCX_REQUIRE(r && l && c, "mpcx_aby3_matmul_local: empty shape");
     MPCX_REQUIRE(layout == 0 || layout == 1, "mpcx_aby3_matmul_local: layout must be 0 or 1");
-    return aby3_matmul_impl(ctx, X0, X1, Y0, Y1, r, l, c, layout, 0, seed_next, pop_next, seed_prev, pop_prev, Z0);
+    return aby3_matmul_impl(ctx, X0, X1, Y0, Y1, r, l, c, layout, layout, 0, seed_next, pop_next, seed_prev, pop_prev, Z0);
+}
+
+// A second operand that many products use (weights): the share pair stays where the caller keeps it on the device, and
+// when products of this shape can run in the residue form, the residue planes of [Y0 + Y1 ; Y0] are made once here.
+struct mpcx_aby3_operand {
+    const i64 *Y0, *Y1;
+    u64 l, c;
+    int layout;
+    RnsPreB pre;
+};
+int mpcx_aby3_operand_prepare(mpcx_ctx *ctx, const int64_t *Y0, const int64_t *Y1, uint64_t l, uint64_t c, int layout,
+                              mpcx_aby3_operand **out) {
+    MPCX_REQUIRE(ctx && Y0 && Y1 && out, "mpcx_aby3_operand_prepare: NULL argument");
+    MPCX_REQUIRE(l && c, "mpcx_aby3_operand_prepare: empty shape");
+    MPCX_REQUIRE(layout == 0 || layout == 1, "mpcx_aby3_operand_prepare: layout must be 0 or 1");
+    mpcx_aby3_operand *op = new mpcx_aby3_operand{Y0, Y1, l, c, layout, RnsPreB()};
+    // worth the memory (18 bytes per word of [Y0 + Y1 ; Y0] against 16 for the pair) only where a product with many rows
+    // would take the residue form at all
+    if (ring_gemm_use_rns(2, 16384, l, c)) {
+        const GemmPart parts[2] = {{nullptr, Y0, Y1}, {nullptr, Y0, nullptr}};
+        if (ring_gemm_rns_prepare_b(ctx, parts, 2, l, c, layout, &op->pre) != 0) {
+            delete op;
+            return 1;
+        }
+    }
+    *out = op;
+    return 0;
+}
+int mpcx_aby3_operand_free(mpcx_ctx *ctx, mpcx_aby3_operand *op) {
+    if (!op) return 0;
+    MPCX_REQUIRE(ctx, "mpcx_aby3_operand_free: the context is NULL");
+    ring_gemm_rns_release_b(ctx, &op->pre);
+    delete op;
+    return 0;
+}
+uint64_t mpcx_aby3_operand_bytes(const mpcx_aby3_operand *op) { return op ? op->pre.nchunks * op->pre.chunk_bytes : 0; }
+uint64_t mpcx_aby3_operand_uses(const mpcx_aby3_operand *op) { return op ? op->pre.used : 0; }
+int mpcx_aby3_matmul_local_prepared(mpcx_ctx *ctx, const int64_t *X0, const int64_t *X1, int layoutX,
+                                    const mpcx_aby3_operand *Y, uint64_t rows, uint64_t row0, uint64_t seed_next,
+                                    uint64_t pop_next, uint64_t seed_prev, uint64_t pop_prev, int64_t *Z0) {
+    MPCX_REQUIRE(X0 && X1 && Y && Z0, "mpcx_aby3_matmul_local_prepared: NULL operand");
+    MPCX_REQUIRE(rows, "mpcx_aby3_matmul_local_prepared: empty shape");
+    MPCX_REQUIRE(layoutX == 0 || layoutX == 1, "mpcx_aby3_matmul_local_prepared: layout must be 0 or 1");
+    return aby3_matmul_impl(ctx, X0, X1, Y->Y0, Y->Y1, rows, Y->l, Y->c, layoutX, Y->layout, row0 * Y->c, seed_next, pop_next,
+                            seed_prev, pop_prev, Z0, &Y->pre);
 }
 
 int mpcx_aby3_vecmul_local(mpcx_ctx *ctx, const int64_t *X0, const int64_t *X1, const int64_t *Y0, const int64_t *Y1,

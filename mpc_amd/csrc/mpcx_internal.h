@@ -172,8 +172,9 @@ struct GemmPart {
     const i64 *A;
     const i64 *B, *Bplus; // Bplus (nullable) is added element-wise to B before the limb split
 };
+struct RnsPreB;
 int ring_gemm_parts(mpcx_ctx *ctx, const GemmPart *parts, int nparts, u64 r, u64 l, u64 c, int layA, int layB,
-                    const i64 *add, const i64 *sub, i64 *Z, int layZ, int accumulate);
+                    const i64 *add, const i64 *sub, i64 *Z, int layZ, int accumulate, const RnsPreB *pre = nullptr);
 // workspace bytes ring_gemm_parts takes from the front of the context workspace (a caller may reserve
 // more and use the tail for itself)
 u64 ring_gemm_ws_bytes(int nparts, u64 r, u64 l, u64 c);
@@ -184,5 +185,18 @@ u32 gemm_group_rows(const char *env_name, u32 tiles_m);
 // looks up, once per device, the address of the file-scope scratch array of the entry point that allocates nothing
 int ring_gemm_static_scratch_init(int device);
 u64 ring_gemm_rns_ws_bytes(int nparts, u64 r, u64 l, u64 c);
+// The residue planes of a product's second operand, split once and kept: a product of any row count that runs in the
+// residue form reads them instead of splitting B again (weights that many products use).  They belong to one
+// (nparts, l, c, layout-independent) geometry and block tile; a product they do not fit splits B as usual.
+struct RnsPreB {
+    i8 *planes = nullptr; // nchunks x chunk_bytes, one K chunk after the other
+    u64 chunk_bytes = 0, nchunks = 0;
+    int nparts = 0;
+    u64 l = 0, c = 0;
+    bool wide = false;
+    mutable u64 used = 0; // products that read the planes
+};
+int ring_gemm_rns_prepare_b(mpcx_ctx *ctx, const GemmPart *parts, int nparts, u64 l, u64 c, int layB, RnsPreB *out);
+void ring_gemm_rns_release_b(mpcx_ctx *ctx, RnsPreB *pre);
 int ring_gemm_parts_rns(mpcx_ctx *ctx, const GemmPart *parts, int nparts, u64 r, u64 l, u64 c, int layA, int layB,
-                        const i64 *add, const i64 *sub, i64 *Z, int layZ, int accumulate);
+                        const i64 *add, const i64 *sub, i64 *Z, int layZ, int accumulate, const RnsPreB *pre = nullptr);

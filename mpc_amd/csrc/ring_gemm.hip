@@ -407,9 +407,9 @@ static int ring_gemm_positional(mpcx_ctx *ctx, const GemmPart *parts, int nparts
                                 const i64 *add, const i64 *sub, i64 *Z, int layZ, int accumulate, void *ws);
 
 int ring_gemm_parts(mpcx_ctx *ctx, const GemmPart *parts, int nparts, u64 r, u64 l, u64 c, int layA, int layB,
-                    const i64 *add, const i64 *sub, i64 *Z, int layZ, int accumulate) {
+                    const i64 *add, const i64 *sub, i64 *Z, int layZ, int accumulate, const RnsPreB *pre) {
     if (r && l && c && ring_gemm_use_rns(nparts, r, l, c))
-        return ring_gemm_parts_rns(ctx, parts, nparts, r, l, c, layA, layB, add, sub, Z, layZ, accumulate);
+        return ring_gemm_parts_rns(ctx, parts, nparts, r, l, c, layA, layB, add, sub, Z, layZ, accumulate, pre);
     MPCX_REQUIRE(r > 0 && l > 0 && c > 0, "ring gemm: empty operand (r=%llu l=%llu c=%llu)", (unsigned long long)r,
                  (unsigned long long)l, (unsigned long long)c);
     void *ws;

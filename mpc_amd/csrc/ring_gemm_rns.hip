@@ -701,8 +701,62 @@ u64 ring_gemm_rns_ws_bytes(int nparts, u64 r, u64 l, u64 c) {
     return a + b + y;
 }
 
+// splits the second operands of one K chunk [kb, kb + klen) into the planes at Bpl
+static void rns_split_b_chunk(mpcx_ctx *ctx, const GemmPart *parts, int nparts, u64 c, u64 l, int layB, u64 kb, u64 klen,
+                              const RnsGeom &geom, i8 *Bpl, const RnsTab &T) {
+    const u64 soB = layB ? l : 1, skB = layB ? 1 : c;
+    SplitJobs jobs;
+    u32 n = 0;
+    for (int p = 0; p < nparts; p++) {
+        const u64 cover = p + 1 == nparts ? geom.Kp - (u64)p * geom.lc : geom.lc;
+        jobs.j[n++] = SplitJob{(const u64 *)parts[p].B + kb * skB,
+                               parts[p].Bplus ? (const u64 *)parts[p].Bplus + kb * skB : nullptr, Bpl, c, soB, skB, geom.Np,
+                               (u64)p * geom.lc, cover};
+    }
+    const u32 gx = (u32)ceil_div(geom.Kp - (u64)(nparts - 1) * geom.lc, 64);
+    if (skB == 1)
+        hipLaunchKernelGGL(rns_split_kernel<true>, dim3(gx, (u32)(geom.Np / 64), n), dim3(256), 0, ctx->stream, jobs, klen,
+                           geom.Kp, T);
+    else
+        hipLaunchKernelGGL(rns_split_kernel<false>, dim3(gx, (u32)(geom.Np / 64), n), dim3(256), 0, ctx->stream, jobs, klen,
+                           geom.Kp, T);
+}
+
+int ring_gemm_rns_prepare_b(mpcx_ctx *ctx, const GemmPart *parts, int nparts, u64 l, u64 c, int layB, RnsPreB *out) {
+    MPCX_REQUIRE(l > 0 && c > 0 && l < (1u << 30) && c < (1u << 30), "ring gemm: bad operand shape");
+    MPCX_REQUIRE(nparts >= 1 && nparts <= 8, "ring gemm: bad part count");
+    const RnsTab &T = rns_tab();
+    const RnsGeom geom = rns_geom(nparts, 1, l, c);
+    MPCX_REQUIRE((u64)nparts * geom.lc <= 8192, "ring gemm: cannot chunk K");
+    MPCX_REQUIRE(geom.Np / 64 <= 65535, "ring gemm: more than 4194240 columns");
+    RnsPreB pre;
+    pre.chunk_bytes = (NP * geom.Np * geom.Kp + 255) & ~255ull;
+    pre.nchunks = ceil_div(l, geom.lc);
+    pre.nparts = nparts, pre.l = l, pre.c = c, pre.wide = geom.wide;
+    void *mem = nullptr;
+    MPCX_TRY(mpcx_malloc(ctx, pre.nchunks * pre.chunk_bytes, &mem));
+    pre.planes = (i8 *)mem;
+    {
+        ProfScope ps(ctx, PROF_SPLIT);
+        u64 ci = 0;
+        for (u64 kb = 0; kb < l; kb += geom.lc, ci++)
+            rns_split_b_chunk(ctx, parts, nparts, c, l, layB, kb, (l - kb < geom.lc) ? l - kb : geom.lc, geom,
+                              pre.planes + ci * pre.chunk_bytes, T);
+    }
+    if (hipGetLastError() != hipSuccess) {
+        (void)mpcx_free(ctx, mem);
+        MPCX_REQUIRE(false, "ring gemm: the split of a resident operand failed to launch");
+    }
+    *out = pre;
+    return 0;
+}
+void ring_gemm_rns_release_b(mpcx_ctx *ctx, RnsPreB *pre) {
+    if (pre && pre->planes) (void)mpcx_free(ctx, pre->planes);
+    if (pre) *pre = RnsPreB();
+}
+
 int ring_gemm_parts_rns(mpcx_ctx *ctx, const GemmPart *parts, int nparts, u64 r, u64 l, u64 c, int layA, int layB,
-                        const i64 *add, const i64 *sub, i64 *Z, int layZ, int accumulate) {
+                        const i64 *add, const i64 *sub, i64 *Z, int layZ, int accumulate, const RnsPreB *pre) {
     MPCX_REQUIRE(r > 0 && l > 0 && c > 0, "ring gemm: empty operand (r=%llu l=%llu c=%llu)", (unsigned long long)r,
                  (unsigned long long)l, (unsigned long long)c);
     MPCX_REQUIRE(r < (1u << 30) && c < (1u << 30) && l < (1u << 30), "ring gemm: dimension too large");
@@ -724,9 +778,16 @@ int ring_gemm_parts_rns(mpcx_ctx *ctx, const GemmPart *parts, int nparts, u64 r,
     const u64 soA = layA ? 1 : l, skA = layA ? r : 1;
     const u64 soB = layB ? l : 1, skB = layB ? 1 : c;
     const u32 gm = gemm_group_rows("MPCX_RNS_GM", tiles_m); // tile rows per group (tuning)
+    // planes of the second operand made earlier for exactly this geometry are read in place of a split of B
+    const bool have_b = pre && pre->planes && pre->nparts == nparts && pre->l == l && pre->c == c && pre->wide == geom.wide &&
+                        pre->chunk_bytes == ((NP * Np * Kp + 255) & ~255ull) && pre->nchunks == ceil_div(l, lc);
+    if (have_b) pre->used++;
+    i8 *const Bws = Bpl;
     int first = 1;
-    for (u64 kb = 0; kb < l; kb += lc) {
+    u64 chunk = 0;
+    for (u64 kb = 0; kb < l; kb += lc, chunk++) {
         const u64 klen = (l - kb < lc) ? l - kb : lc;
+        Bpl = have_b ? pre->planes + chunk * pre->chunk_bytes : Bws;
         {
             ProfScope ps(ctx, PROF_SPLIT);
             SplitJobs fast, slow;
@@ -739,7 +800,9 @@ int ring_gemm_parts_rns(mpcx_ctx *ctx, const GemmPart *parts, int nparts, u64 r,
                 const SplitJob jb{(const u64 *)parts[p].B + kb * skB,
                                   parts[p].Bplus ? (const u64 *)parts[p].Bplus + kb * skB : nullptr, Bpl, c, soB, skB, Np,
                                   (u64)p * lc, cover};
-                for (const SplitJob &j : {ja, jb}) {
+                const SplitJob both[2] = {ja, jb};
+                for (int q = 0; q < (have_b ? 1 : 2); q++) {
+                    const SplitJob &j = both[q];
                     if (j.sk == 1) {
                         fast.j[nfast++] = j;
                         if (j.Op > fast_op) fast_op = j.Op;

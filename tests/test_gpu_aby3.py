@@ -199,6 +199,64 @@ def test_aby3_matmul_row_blocks_equal_whole(gpu, orc):
     assert np.array_equal(np.concatenate(parts), whole)
 
 
+@pytest.mark.parametrize("mode,tile_at_use", [("2", None), ("2", "0"), ("1", None), ("0", None)])
+@pytest.mark.parametrize("rows,l,c,lay_x,lay_y,row0", [(300, 2100, 1100, 0, 0, 0), (130, 700, 260, 1, 1, 5),
+                                                         (64, 5000, 300, 0, 1, 17), (1030, 2048, 1024, 1, 0, 0)])
+def test_aby3_matmul_with_a_prepared_second_operand(gpu, orc, rows, l, c, lay_x, lay_y, row0, mode, tile_at_use, monkeypatch):
+    """mpcx_aby3_operand_prepare + mpcx_aby3_matmul_local_prepared = the ordinary segment, word for word: with the
+    residue form forced (planes made once and read by two products with different row counts; l = 5000 runs as two
+    accumulation chunks), with the block tile switched between preparation and use (the planes no longer fit and the
+    product splits its operand itself), with the formulation chosen by the library, and with the digit-pair form
+    forced (no planes are made)."""
+    import ctypes
+    ctx = gpu.ctx
+    monkeypatch.setenv("MPCX_GEMM_RNS", mode)
+    rng = np.random.default_rng(rows + l + c)
+    Y0, Y1 = rnd(rng, l * c), rnd(rng, l * c)
+    to_lay = lambda M, a, b, lay: np.ascontiguousarray(M.reshape(a, b).T).ravel() if lay else M
+    dY0, dY1 = ctx.to_device(to_lay(Y0, l, c, lay_y)), ctx.to_device(to_lay(Y1, l, c, lay_y))
+    op = ctypes.c_void_p()
+    U64 = ctypes.c_uint64
+    ctx._call("mpcx_aby3_operand_prepare", ctypes.c_void_p(dY0.ptr), ctypes.c_void_p(dY1.ptr), U64(l), U64(c),
+              ctypes.c_int(lay_y), ctypes.byref(op))
+    ctx.lib.mpcx_aby3_operand_bytes.restype = ctypes.c_uint64
+    held = ctx.lib.mpcx_aby3_operand_bytes(op)
+    if mode == "2":
+        assert held >= 18 * 2 * l * c  # the planes of [Y0 + Y1 ; Y0]
+    if mode == "0":
+        assert held == 0
+    if tile_at_use is not None:
+        monkeypatch.setenv("MPCX_RNS_TILE", tile_at_use)
+    try:
+        for rr in (rows, max(1, rows // 3)):
+            X0, X1 = rnd(rng, rr * l), rnd(rng, rr * l)
+            want = orc.aby3_matmul_local_rows(X0, X1, Y0, Y1, rr, l, c, row0, KEY01, 11, KEY20, 7) \
+                if hasattr(orc, "aby3_matmul_local_rows") else None
+            dX0, dX1 = ctx.to_device(to_lay(X0, rr, l, lay_x)), ctx.to_device(to_lay(X1, rr, l, lay_x))
+            Z = ctx.empty(np.int64, rr * c)
+            ctx._call("mpcx_aby3_matmul_local_prepared", ctypes.c_void_p(dX0.ptr), ctypes.c_void_p(dX1.ptr),
+                      ctypes.c_int(lay_x), op, U64(rr), U64(row0), U64(KEY01), U64(11), U64(KEY20), U64(7),
+                      ctypes.c_void_p(Z.ptr))
+            plain = gpu.aby3_matmul_local_rows(X0, X1, Y0, Y1, rr, l, c, row0, KEY01, 11, KEY20, 7)
+            got = Z.to_host()
+            assert np.array_equal(got, plain), "prepared product differs from the ordinary segment"
+            if want is not None:
+                assert np.array_equal(got, want)
+            else:  # the oracle has no row-block form: the mask is pops [row0 c, ..) of both streams, the product exact
+                from oracle_lib import prg_pops
+                mask = prg_pops(KEY01, 11 + row0 * c, rr * c) - prg_pops(KEY20, 7 + row0 * c, rr * c)
+                with np.errstate(over="ignore"):
+                    assert np.array_equal(got, orc.ring_gemm(X0, Y0 + Y1, rr, l, c) + orc.ring_gemm(X1, Y0, rr, l, c) + mask)
+        ctx.lib.mpcx_aby3_operand_uses.restype = ctypes.c_uint64
+        uses = ctx.lib.mpcx_aby3_operand_uses(op)
+        if mode == "2":
+            assert uses == (2 if tile_at_use is None else 0)  # both products read the planes / neither could
+        if mode == "0":
+            assert uses == 0
+    finally:
+        ctx._call("mpcx_aby3_operand_free", op)
+
+
 @pytest.mark.parametrize("fused", [True, False])  # msb as one call per messenger gap, or as separate post / pre calls
 @pytest.mark.parametrize("n", [1, 4, 63, 64, 65, 1000, 4097, (1 << 20) + 4099])  # the last: every kernel grid-strides
 def test_aby3_relu_chain_parity(gpu, orc, n, fused, monkeypatch):
