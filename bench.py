@@ -775,7 +775,23 @@ def config5_slice(ctx, torch, dev):
     y0v = matvec(RY[0].view(l, c), v)
     assert torch.equal(matvec(P, v), matvec(RX[0].view(rows, l), ysv) + matvec(RX[1].view(rows, l), y0v)), \
         "config 5 row block: P v != X0 ((Y0 + Y1) v) + X1 (Y0 v)"
-    del P, RX, RY, Z, ysv, y0v
+    # the same call with Y as a resident second operand (weights that many products use): its residue planes are made
+    # once and the product splits only X
+    op = ctypes.c_void_p()
+    U64 = ctypes.c_uint64
+    ctx._call("mpcx_aby3_operand_prepare", ctypes.c_void_p(RY[0].data_ptr()), ctypes.c_void_p(RY[1].data_ptr()), U64(l), U64(c),
+              ctypes.c_int(0), ctypes.byref(op))
+    Zp = e(rows * c)
+    prepared = lambda: ctx._call("mpcx_aby3_matmul_local_prepared", ctypes.c_void_p(RX[0].data_ptr()),
+                                 ctypes.c_void_p(RX[1].data_ptr()), ctypes.c_int(0), op, U64(rows), U64(row0), U64(KEY01),
+                                 U64(plan["matmul"]), U64(KEY20), U64(plan["matmul"]), ctypes.c_void_p(Zp.data_ptr()))
+    prepared()
+    dtp, _ = _timed(torch, prepared, reps=reps)
+    assert torch.equal(Zp, Z), "config 5 row block: the product with a prepared operand differs"
+    lib.mpcx_aby3_operand_bytes.restype = ctypes.c_uint64
+    plane_bytes = lib.mpcx_aby3_operand_bytes(op)
+    ctx._call("mpcx_aby3_operand_free", op)
+    del P, RX, RY, Z, Zp, ysv, y0v
     torch.cuda.empty_cache()
     out["matmul_row_block"] = {
         "shape": f"{rows}x{l} . {l}x{c} (rows [{row0}, {row0 + rows}) of {full}), one party's matrix_mul segment",
@@ -784,7 +800,9 @@ def config5_slice(ctx, torch, dev):
         "algorithmic_TOPs": round(alg, 1), "frac": round(alg / INT8_PEAK_TOPS, 4),
         "issued_frac": round(alg * nprod / 36 / INT8_PEAK_TOPS, 4),
         "call_frac": round(ops / dt / 1e12 / INT8_PEAK_TOPS, 4),
-        "ring_Gops": round(3 * 2 * rows * l * c / dt / 1e9, 1), "verified": "Freivalds check of the unmasked block"}
+        "ring_Gops": round(3 * 2 * rows * l * c / dt / 1e9, 1), "verified": "Freivalds check of the unmasked block",
+        "ms_second_operand_prepared": round(dtp * 1e3, 3), "prepared_call_frac": round(ops / dtp / 1e12 / INT8_PEAK_TOPS, 4),
+        "prepared_planes_GiB": round(plane_bytes / 2 ** 30, 2)}
 
     be = ResidentBackend(ctx, torch, dev)
     x = torch.empty(n, dtype=torch.int64, device=dev)

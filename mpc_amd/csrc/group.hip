@@ -28,10 +28,12 @@ struct mpcx_group {
 };
 
 // A replicated operand of matrix products (both shares of Y, row-major) that every member of a group holds on its
-// device from mpcx_group_operand_upload until mpcx_group_operand_free.
+// device from mpcx_group_operand_upload until mpcx_group_operand_free, together with its residue planes where products
+// of its shape run in the residue form (mpcx_aby3_operand_prepare).
 struct mpcx_group_operand {
     u64 rows, cols;
     std::vector<void *> s0, s1; // per member
+    std::vector<mpcx_aby3_operand *> prepared;
 };
 
 namespace {
@@ -227,9 +229,12 @@ static int group_aby3_matmul(mpcx_group *g, const int64_t *X0, const int64_t *X1
                 G_TRY(mpcx_relayout(ctx, (const i64 *)tmp, (i64 *)py1, l, c, 1, 0));
             }
         }
-        const i64 *y0 = op ? (const i64 *)op->s0[k] : (const i64 *)py0, *y1 = op ? (const i64 *)op->s1[k] : (const i64 *)py1;
-        G_TRY(mpcx_aby3_matmul_local_rows(ctx, (const i64 *)px0, (const i64 *)px1, y0, y1, rows, l, c, row0, seed_next,
-                                          pop_next, seed_prev, pop_prev, (i64 *)pz));
+        if (op)
+            G_TRY(mpcx_aby3_matmul_local_prepared(ctx, (const i64 *)px0, (const i64 *)px1, 0, op->prepared[k], rows, row0,
+                                                  seed_next, pop_next, seed_prev, pop_prev, (i64 *)pz));
+        else
+            G_TRY(mpcx_aby3_matmul_local_rows(ctx, (const i64 *)px0, (const i64 *)px1, (const i64 *)py0, (const i64 *)py1,
+                                              rows, l, c, row0, seed_next, pop_next, seed_prev, pop_prev, (i64 *)pz));
         G_TRY(mpcx_d2h(ctx, Z0 + row0 * c, pz, 8 * rows * c)); // straight into the caller's (messenger-facing) buffer
 #undef G_TRY
         return release(0);
@@ -271,17 +276,24 @@ int mpcx_group_operand_upload(mpcx_group *g, const int64_t *M0, const int64_t *M
     op->rows = rows, op->cols = cols;
     op->s0.assign(members, nullptr);
     op->s1.assign(members, nullptr);
+    op->prepared.assign(members, nullptr);
     const int rc = group_run(g, members, [=](int k) -> int {
         mpcx_ctx *ctx = g->ctx[k];
         void *tmp = nullptr;
         if (mpcx_malloc(ctx, 8 * rows * cols, &op->s0[k]) || mpcx_malloc(ctx, 8 * rows * cols, &op->s1[k])) return 1;
-        if (layout == 0) return mpcx_h2d(ctx, op->s0[k], M0, 8 * rows * cols) || mpcx_h2d(ctx, op->s1[k], M1, 8 * rows * cols);
-        if (mpcx_malloc(ctx, 8 * rows * cols, &tmp)) return 1;
-        int rc2 = mpcx_h2d(ctx, tmp, M0, 8 * rows * cols);
-        if (!rc2) rc2 = mpcx_relayout(ctx, (const i64 *)tmp, (i64 *)op->s0[k], rows, cols, 1, 0);
-        if (!rc2) rc2 = mpcx_h2d(ctx, tmp, M1, 8 * rows * cols); // ordered behind the relayout on the context's stream
-        if (!rc2) rc2 = mpcx_relayout(ctx, (const i64 *)tmp, (i64 *)op->s1[k], rows, cols, 1, 0);
-        (void)mpcx_free(ctx, tmp);
+        int rc2 = 0;
+        if (layout == 0) {
+            rc2 = mpcx_h2d(ctx, op->s0[k], M0, 8 * rows * cols) || mpcx_h2d(ctx, op->s1[k], M1, 8 * rows * cols);
+        } else {
+            if (mpcx_malloc(ctx, 8 * rows * cols, &tmp)) return 1;
+            rc2 = mpcx_h2d(ctx, tmp, M0, 8 * rows * cols);
+            if (!rc2) rc2 = mpcx_relayout(ctx, (const i64 *)tmp, (i64 *)op->s0[k], rows, cols, 1, 0);
+            if (!rc2) rc2 = mpcx_h2d(ctx, tmp, M1, 8 * rows * cols); // ordered behind the relayout on the context's stream
+            if (!rc2) rc2 = mpcx_relayout(ctx, (const i64 *)tmp, (i64 *)op->s1[k], rows, cols, 1, 0);
+            (void)mpcx_free(ctx, tmp);
+        }
+        if (!rc2)
+            rc2 = mpcx_aby3_operand_prepare(ctx, (const i64 *)op->s0[k], (const i64 *)op->s1[k], rows, cols, 0, &op->prepared[k]);
         return rc2;
     });
     if (rc) {
@@ -296,6 +308,7 @@ int mpcx_group_operand_free(mpcx_group *g, mpcx_group_operand *op) {
     if (!op) return 0;
     if (g)
         for (size_t k = 0; k < op->s0.size() && k < g->ctx.size(); k++) {
+            (void)mpcx_aby3_operand_free(g->ctx[k], op->prepared[k]);
             (void)mpcx_free(g->ctx[k], op->s0[k]);
             (void)mpcx_free(g->ctx[k], op->s1[k]);
         }

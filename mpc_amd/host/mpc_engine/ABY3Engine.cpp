@@ -33,7 +33,10 @@ struct ABY3Engine::Pinned {
     std::unique_ptr<Dev<int64_t>> s0, s1;
     mpcx_group *group = nullptr;
     mpcx_group_operand *gop = nullptr;
-    Pinned(mpcx_ctx *ctx, mpcx_group *g, const MatPair &M) : key(&M), rows(M[0].rows()), cols(M[0].cols()), group(g) {
+    mpcx_ctx *ctx = nullptr;
+    // the pair as a product's second operand (residue planes where the library uses them), made at its first use as one
+    mpcx_aby3_operand *as_second = nullptr;
+    Pinned(mpcx_ctx *c, mpcx_group *g, const MatPair &M) : key(&M), rows(M[0].rows()), cols(M[0].cols()), group(g), ctx(c) {
         if (group) {
             if (mpcx_group_operand_upload(group, M[0].data(), M[1].data(), rows, cols, 1, &gop) != 0) {
                 fprintf(stderr, "mpcx_group_operand_upload: %s\n", mpcx_group_last_error(group));
@@ -45,6 +48,7 @@ struct ABY3Engine::Pinned {
         }
     }
     ~Pinned() {
+        if (as_second) mpcx_aby3_operand_free(ctx, as_second);
         if (gop) mpcx_group_operand_free(group, gop);
     }
 };
@@ -400,7 +404,8 @@ void ABY3Engine::matrix_mul(const array<MatrixXl, 2> &Xj, const array<MatrixXl, 
         Dev<int64_t> z(gpu, rows * cols);
         std::unique_ptr<mpcgpu::Span> up(new mpcgpu::Span("matrix_mul: upload"));
         // operands the caller pinned are on the device already
-        const Pinned *px = find_pinned(Xj), *py = find_pinned(Yj);
+        const Pinned *px = find_pinned(Xj);
+        Pinned *py = find_pinned(Yj);
         assert(!px || (px->rows == rows && px->cols == lens));
         assert(!py || (py->rows == lens && py->cols == cols));
         std::unique_ptr<Dev<int64_t>> ux0, ux1, uy0, uy1;
@@ -414,12 +419,17 @@ void ABY3Engine::matrix_mul(const array<MatrixXl, 2> &Xj, const array<MatrixXl, 
         }
         const int64_t *x0 = px ? px->s0->p : ux0->p, *x1 = px ? px->s1->p : ux1->p;
         const int64_t *y0 = py ? py->s0->p : uy0->p, *y1 = py ? py->s1->p : uy1->p;
+        if (py && !py->as_second) GPU_OK(gpu, mpcx_aby3_operand_prepare(gpu, y0, y1, lens, cols, 1, &py->as_second));
         up.reset();
         // Eigen stores column-major (layout 1); the result comes back row-major = the wire order
         {
             mpcgpu::Span s2("matrix_mul: product");
-            GPU_OK(gpu, mpcx_aby3_matmul_local(gpu, x0, x1, y0, y1, rows, lens, cols, 1, prgs[pe.next].init_seed,
-                                               prgs[pe.next].pops, prgs[pe.prev].init_seed, prgs[pe.prev].pops, z));
+            if (py)
+                GPU_OK(gpu, mpcx_aby3_matmul_local_prepared(gpu, x0, x1, 1, py->as_second, rows, 0, prgs[pe.next].init_seed,
+                                                            prgs[pe.next].pops, prgs[pe.prev].init_seed, prgs[pe.prev].pops, z));
+            else
+                GPU_OK(gpu, mpcx_aby3_matmul_local(gpu, x0, x1, y0, y1, rows, lens, cols, 1, prgs[pe.next].init_seed,
+                                                   prgs[pe.next].pops, prgs[pe.prev].init_seed, prgs[pe.prev].pops, z));
             if (mpcgpu::Span::on()) GPU_OK(gpu, mpcx_sync(gpu)); // so that the span is the product's own time
         }
         mpcgpu::Span s3("matrix_mul: download");
