@@ -337,6 +337,7 @@ struct mpcx_aby3_operand {
     const i64 *Y0, *Y1;
     u64 l, c;
     int layout;
+    int device; // the planes live on the device of the context that made them
     RnsPreB pre;
 };
 int mpcx_aby3_operand_prepare(mpcx_ctx *ctx, const int64_t *Y0, const int64_t *Y1, uint64_t l, uint64_t c, int layout,
@@ -344,7 +345,7 @@ int mpcx_aby3_operand_prepare(mpcx_ctx *ctx, const int64_t *Y0, const int64_t *Y
     MPCX_REQUIRE(ctx && Y0 && Y1 && out, "mpcx_aby3_operand_prepare: NULL argument");
     MPCX_REQUIRE(l && c, "mpcx_aby3_operand_prepare: empty shape");
     MPCX_REQUIRE(layout == 0 || layout == 1, "mpcx_aby3_operand_prepare: layout must be 0 or 1");
-    mpcx_aby3_operand *op = new mpcx_aby3_operand{Y0, Y1, l, c, layout, RnsPreB()};
+    mpcx_aby3_operand *op = new mpcx_aby3_operand{Y0, Y1, l, c, layout, ctx->device, RnsPreB()};
     // worth the memory (18 bytes per word of [Y0 + Y1 ; Y0] against 16 for the pair) only where a product with many rows
     // would take the residue form at all
     if (ring_gemm_use_rns(2, 16384, l, c)) {
@@ -372,6 +373,8 @@ int mpcx_aby3_matmul_local_prepared(mpcx_ctx *ctx, const int64_t *X0, const int6
     MPCX_REQUIRE(X0 && X1 && Y && Z0, "mpcx_aby3_matmul_local_prepared: NULL operand");
     MPCX_REQUIRE(rows, "mpcx_aby3_matmul_local_prepared: empty shape");
     MPCX_REQUIRE(layoutX == 0 || layoutX == 1, "mpcx_aby3_matmul_local_prepared: layout must be 0 or 1");
+    MPCX_REQUIRE(Y->device == ctx->device, "mpcx_aby3_matmul_local_prepared: the operand was prepared on device %d, the context "
+                 "works on device %d", Y->device, ctx->device);
     return aby3_matmul_impl(ctx, X0, X1, Y->Y0, Y->Y1, rows, Y->l, Y->c, layoutX, Y->layout, row0 * Y->c, seed_next, pop_next,
                             seed_prev, pop_prev, Z0, &Y->pre);
 }
