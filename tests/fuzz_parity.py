@@ -1,6 +1,6 @@
 """Randomised parity campaign (run by hand on a GPU box: `python tests/fuzz_parity.py [iterations] [seed]`; not collected
-by pytest).  Every iteration draws one case -- a ring product of random shape / layouts / formulation / block tile, an
-ABY3 ReLU chain, a SecureNN msb or a MyEngine ReLU chain of random length, whole or cut into random element ranges,
+by pytest).  Every iteration draws one case -- a ring product of random shape / layouts / formulation / block tile, an ABY3 product with a
+prepared second operand, an ABY3 ReLU chain, a SecureNN msb or a MyEngine ReLU chain of random length, whole or cut into random element ranges,
 with the fused or the separate segment calls and the generator-byte cache on or off -- runs it on the HIP path and on
 the CPU oracle and requires identical messages and shares."""
 import os
@@ -48,6 +48,45 @@ def case_gemm(rng, gpu, orc):
     want = orc.ring_gemm(A, B, r, l, c, la, lb, lc, C=C)
     assert np.array_equal(got, want), ("gemm", r, l, c, la, lb, lc, acc, os.environ["MPCX_GEMM_RNS"], os.environ["MPCX_RNS_TILE"])
     return f"gemm {r}x{l}x{c} lay {la}{lb}{lc} acc {acc} rns {os.environ['MPCX_GEMM_RNS']} tile {os.environ['MPCX_RNS_TILE']}"
+
+
+def case_prepared_matmul(rng, gpu, orc):
+    """ABY3 matrix_mul segment with the second operand prepared once and used by two or three products of different row
+    counts and row offsets, the block tile possibly switched in between (the planes then no longer fit)."""
+    import ctypes
+    from oracle_lib import prg_pops
+    ctx = gpu.ctx
+    l, c = int(rng.integers(1, 900)), int(rng.integers(1, 700))
+    if rng.random() < 0.25:
+        l = int(rng.integers(900, 6000))
+    lay_x, lay_y = (int(v) for v in rng.integers(0, 2, 2))
+    os.environ["MPCX_GEMM_RNS"] = str(rng.choice(["0", "2", "2", "1"]))
+    os.environ["MPCX_RNS_TILE"] = str(rng.choice(["0", "1"]))
+    to_lay = lambda M, a, b, lay: np.ascontiguousarray(M.reshape(a, b).T).ravel() if lay else M
+    Y0, Y1 = rnd(rng, l * c), rnd(rng, l * c)
+    dY0, dY1 = ctx.to_device(to_lay(Y0, l, c, lay_y)), ctx.to_device(to_lay(Y1, l, c, lay_y))
+    op, U64 = ctypes.c_void_p(), ctypes.c_uint64
+    ctx._call("mpcx_aby3_operand_prepare", ctypes.c_void_p(dY0.ptr), ctypes.c_void_p(dY1.ptr), U64(l), U64(c),
+              ctypes.c_int(lay_y), ctypes.byref(op))
+    try:
+        for _ in range(int(rng.integers(2, 4))):
+            if rng.random() < 0.3:
+                os.environ["MPCX_RNS_TILE"] = str(rng.choice(["0", "1"]))
+            rows, row0 = int(rng.integers(1, 500)), int(rng.integers(0, 50))
+            pn, pp = int(rng.integers(0, 1000)), int(rng.integers(0, 1000))
+            X0, X1 = rnd(rng, rows * l), rnd(rng, rows * l)
+            dX0, dX1 = ctx.to_device(to_lay(X0, rows, l, lay_x)), ctx.to_device(to_lay(X1, rows, l, lay_x))
+            Z = ctx.empty(np.int64, rows * c)
+            ctx._call("mpcx_aby3_matmul_local_prepared", ctypes.c_void_p(dX0.ptr), ctypes.c_void_p(dX1.ptr),
+                      ctypes.c_int(lay_x), op, U64(rows), U64(row0), U64(0xAB01), U64(pn), U64(0xCA20), U64(pp),
+                      ctypes.c_void_p(Z.ptr))
+            mask = prg_pops(0xAB01, pn + row0 * c, rows * c) - prg_pops(0xCA20, pp + row0 * c, rows * c)
+            with np.errstate(over="ignore"):
+                want = orc.ring_gemm(X0, Y0 + Y1, rows, l, c) + orc.ring_gemm(X1, Y0, rows, l, c) + mask
+            assert np.array_equal(Z.to_host(), want), ("prepared", rows, l, c, lay_x, lay_y, row0, os.environ["MPCX_GEMM_RNS"])
+    finally:
+        ctx._call("mpcx_aby3_operand_free", op)
+    return f"prepared matmul l {l} c {c} lay {lay_x}{lay_y} rns {os.environ['MPCX_GEMM_RNS']}"
 
 
 def case_aby3_relu(rng, gpu, orc):
@@ -121,8 +160,8 @@ def main():
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     rng = np.random.default_rng(seed)
     gpu, orc, gmy, omy = GpuBackend(), OracleBackend(), GpuMy(), OracleMy()
-    cases = [(case_gemm, (gpu, orc), 0.35), (case_aby3_relu, (gpu, orc), 0.2), (case_snn_msb, (gpu, orc), 0.2),
-             (case_pc, (gpu, orc), 0.15), (case_my_relu, (gmy, omy), 0.1)]
+    cases = [(case_gemm, (gpu, orc), 0.3), (case_prepared_matmul, (gpu, orc), 0.1), (case_aby3_relu, (gpu, orc), 0.2),
+             (case_snn_msb, (gpu, orc), 0.2), (case_pc, (gpu, orc), 0.12), (case_my_relu, (gmy, omy), 0.08)]
     p = np.array([c[2] for c in cases])
     t0 = time.time()
     for it in range(iters):
