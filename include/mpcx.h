@@ -52,6 +52,11 @@ int mpcx_free(mpcx_ctx *ctx, void *p);
 int mpcx_set_pool_limit(mpcx_ctx *ctx, uint64_t max_idle_bytes);
 int mpcx_h2d(mpcx_ctx *ctx, void *dst, const void *src, uint64_t bytes);
 int mpcx_d2h(mpcx_ctx *ctx, void *dst, const void *src, uint64_t bytes);
+/* Boolean payloads: nbits booleans that the device holds as a bit string (bit b of byte b / 8) <-> nbits bytes of 0 / 1
+ * in host memory (the layout of vecbool2string, utils/util.hpp).  d2h_bits reads ceil(nbits / 8) device bytes;
+ * h2d_bits takes bit 0 of every host byte and writes whole 32-bit words, the bits beyond nbits zero. */
+int mpcx_d2h_bits(mpcx_ctx *ctx, void *dst_bytes, const void *src_bits, uint64_t nbits);
+int mpcx_h2d_bits(mpcx_ctx *ctx, void *dst_bits, const void *src_bytes, uint64_t nbits);
 int mpcx_d2d(mpcx_ctx *ctx, void *dst, const void *src, uint64_t bytes);
 /* mpcx_h2d / mpcx_d2h return when the copy is complete; host memory may be pageable (the std::string payloads of
  * VirtuleMessenger::send_and_recv, utils/VirtuleMessenger.hpp:14).  Transfers of 4 MiB and more are pipelined through
@@ -203,6 +208,15 @@ int mpcx_aby3_msb_final(mpcx_ctx *ctx, const uint64_t *state, const int64_t *P0_
 int mpcx_aby3_msb_round_mid(mpcx_ctx *ctx, uint64_t *state, uint64_t n, uint64_t temp, const int8_t *msg_in,
                             int8_t *msg_out);
 int mpcx_aby3_msb_last(mpcx_ctx *ctx, const uint64_t *state, uint64_t n, const int8_t *msg_in, int8_t *Z0, int8_t *Z1);
+/* The same three segments with the messages kept as bit strings on the device: bit b of a string is wire byte b of the
+ * vecbool2string payload (utils/util.hpp), ceil(bits / 32) words per message, bits beyond the message zero.  The wire
+ * bytes are made from / packed into such strings on the host by mpcx_d2h_bits / mpcx_h2d_bits below, so an eighth of
+ * the bytes cross the host link; state, results and the bytes on the wire are those of the byte forms. */
+int mpcx_aby3_msb_round_pre_bits(mpcx_ctx *ctx, uint64_t *state, uint64_t n, uint64_t temp, uint32_t *bits_out);
+int mpcx_aby3_msb_round_mid_bits(mpcx_ctx *ctx, uint64_t *state, uint64_t n, uint64_t temp, const uint32_t *bits_in,
+                                 uint32_t *bits_out);
+int mpcx_aby3_msb_last_bits(mpcx_ctx *ctx, const uint64_t *state, uint64_t n, const uint32_t *bits_in, int8_t *Z0,
+                            int8_t *Z1);
 /* trunc before the round (:480-503); seed12/pop12 = the stream parties 1 and 2 share */
 int mpcx_aby3_trunc_local(mpcx_ctx *ctx, int party, const int64_t *X0, const int64_t *X1, uint64_t n, int number,
                           uint64_t seed12, uint64_t pop12, int64_t *Y0);

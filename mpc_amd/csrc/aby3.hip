@@ -117,7 +117,9 @@ __device__ inline void msb_and32(u32 g0, u32 g1, u32 p0, u32 p1, u32 &re, u32 &r
 }
 
 // FIRST also keeps bit 63 of every P word (`backup`, :385) in two byte arrays bk0 / bk1 for the output step.
-template <bool ALIGNED16, bool FIRST>
+// PACKED: the message stays a bit string (bit b = wire byte b), 32 bits per lane as one word; the bytes of the wire
+// are made from it on the host (mpcx_d2h_bits), so an eighth of the bytes cross the link.
+template <bool ALIGNED16, bool FIRST, bool PACKED = false>
 __global__ __launch_bounds__(256) void msb_round_pre_kernel(MsbIn in, u8 *__restrict__ out, u64 sout, u64 nbits,
                                                             u8 *__restrict__ msg, u8 *__restrict__ bk0,
                                                             u8 *__restrict__ bk1) {
@@ -133,7 +135,10 @@ __global__ __launch_bounds__(256) void msb_round_pre_kernel(MsbIn in, u8 *__rest
         u32 re, ro;
         msb_and32(g0, g1, p0, p1, re, ro);
         const u32 r = re | (ro << 1);
-        if (32 * i + 32 <= nbits) {
+        if (PACKED) {
+            const u64 left = nbits - 32 * i; // bits of the message in this word
+            ((u32 *)msg)[i] = left >= 32 ? r : r & ((1u << left) - 1u);
+        } else if (32 * i + 32 <= nbits) {
             msb_put32<ALIGNED16>(msg + 32 * i, r);
         } else {
             for (u64 t = 32 * i; t < nbits; t++) msg[t] = (u8)((r >> (t & 31)) & 1u);
@@ -171,7 +176,7 @@ __global__ __launch_bounds__(256) void msb_round_post_kernel(MsbIn in, u8 *__res
 // with the 32 bits of share 0 that the previous segment stored they give this party's product share of round T/2
 // (:397-414, :253-256) -- 32 wire bytes -- and 16 bits of share 0 of level T/4.  Of share 1 only G is stored (the
 // next segment reads its odd bits); P1 of a level is never needed again.
-template <bool ALIGNED16, bool FIRST>
+template <bool ALIGNED16, bool FIRST, bool PACKED = false>
 __global__ __launch_bounds__(256) void msb_round_mid_kernel(const u32 *__restrict__ g1_in, u64 g1_words,
                                                             u8 *__restrict__ half, u64 shalf, u8 *__restrict__ quarter,
                                                             u64 squarter, u64 nbits, const u8 *__restrict__ msg_in,
@@ -181,7 +186,10 @@ __global__ __launch_bounds__(256) void msb_round_mid_kernel(const u32 *__restric
     const u64 hbits = nbits / 2; // bits of a level-T/2 string = bytes of the outgoing message
     for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < lanes; i += (u64)gridDim.x * 256) {
         u32 rlo = 0, rhi = 0;
-        if (64 * i + 64 <= nbits) {
+        if (PACKED) { // bits beyond the message are zero (mpcx_h2d_bits)
+            rlo = ((const u32 *)msg_in)[2 * i];
+            rhi = 64 * i + 32 < nbits ? ((const u32 *)msg_in)[2 * i + 1] : 0;
+        } else if (64 * i + 64 <= nbits) {
             rlo = msb_get32<ALIGNED16>(msg_in + 64 * i);
             rhi = msb_get32<ALIGNED16>(msg_in + 64 * i + 32);
         } else {
@@ -203,7 +211,10 @@ __global__ __launch_bounds__(256) void msb_round_mid_kernel(const u32 *__restric
         u32 re, ro;
         msb_and32(G0h, G1h, P0h, P1h, re, ro);
         const u32 r = re | (ro << 1);
-        if (32 * i + 32 <= hbits) {
+        if (PACKED) {
+            const u64 left = hbits - 32 * i;
+            ((u32 *)msg_out)[i] = left >= 32 ? r : r & ((1u << left) - 1u);
+        } else if (32 * i + 32 <= hbits) {
             msb_put32<ALIGNED16>(msg_out + 32 * i, r);
         } else {
             for (u64 t = 32 * i; t < hbits; t++) msg_out[t] = (u8)((r >> (t & 31)) & 1u);
@@ -217,7 +228,7 @@ __global__ __launch_bounds__(256) void msb_round_mid_kernel(const u32 *__restric
 // The segment after the last round: round_post(1) and the output step (:459-466) in one pass, eight elements per
 // lane.  msg = result[1] of round 1 (two bytes per element); g1_lvl1 = G1 of level 1 (two bits per element),
 // g0_lvl0 = G0 of level 0 (one bit per element); bk0 / bk1 = the backup bytes the first round kept.
-template <bool ALIGNED>
+template <bool ALIGNED, bool PACKED = false>
 __global__ __launch_bounds__(256) void msb_last_kernel(const u8 *__restrict__ g1_lvl1, const u8 *__restrict__ g0_lvl0,
                                                        const u8 *__restrict__ msg, const u8 *__restrict__ bk0,
                                                        const u8 *__restrict__ bk1, u64 n, u8 *__restrict__ Z0,
@@ -226,7 +237,14 @@ __global__ __launch_bounds__(256) void msb_last_kernel(const u8 *__restrict__ g1
     for (u64 q = (u64)blockIdx.x * 256 + threadIdx.x; q < groups; q += (u64)gridDim.x * 256) {
         const u64 k0 = 8 * q;
         const u32 g1w = g1_lvl1[2 * q] | (k0 + 4 < n ? (u32)g1_lvl1[2 * q + 1] << 8 : 0), g0w = g0_lvl0[q];
-        if (ALIGNED && k0 + 8 <= n) {
+        if (PACKED) { // two message bits per element: the lane's eight elements are one 16-bit word
+            const u32 mw16 = ((const u16 *)msg)[q];
+            for (u64 k = k0; k < n && k < k0 + 8; k++) {
+                const u32 e = (u32)(k - k0);
+                Z0[k] = (u8)(((g0w >> e) & 1u) ^ bk0[k]);
+                Z1[k] = (u8)((((mw16 >> (2 * e)) & 1u) ^ ((g1w >> (2 * e + 1)) & 1u)) ^ bk1[k]);
+            }
+        } else if (ALIGNED && k0 + 8 <= n) {
             const uint4 m = *(const uint4 *)(msg + 2 * k0);
             const u32 mw[4] = {m.x, m.y, m.z, m.w};
             u64 z0 = *(const u64 *)(bk0 + k0), z1 = *(const u64 *)(bk1 + k0);
@@ -461,6 +479,19 @@ static int msb_level_in(mpcx_ctx *ctx, const char *who, const uint64_t *state, u
     return 0;
 }
 // launches KERNEL<16-byte aligned message, first level> for the round with `temp` pairs
+#define MSB_ROUND_LAUNCH_BITS(KERNEL, MSG)                                                                             \
+    do {                                                                                                               \
+        u8 *st = (u8 *)state;                                                                                          \
+        const u32 T = (u32)temp;                                                                                       \
+        const u64 nbits = 2 * temp * n;                                                                                \
+        const dim3 grid(grid_for(ceil_div(nbits, 32))), block(256);                                                    \
+        const u64 sout = msb_stride(n, T / 2);                                                                         \
+        u8 *out = st + msb_base(n, T / 2);                                                                             \
+        if (T == 32)                                                                                                   \
+            hipLaunchKernelGGL((KERNEL<true, true, true>), grid, block, 0, ctx->stream, in, out, sout, nbits, MSG EXTRA); \
+        else                                                                                                           \
+            hipLaunchKernelGGL((KERNEL<true, false, true>), grid, block, 0, ctx->stream, in, out, sout, nbits, MSG EXTRA); \
+    } while (0)
 #define MSB_ROUND_LAUNCH(KERNEL, MSG)                                                                                  \
     do {                                                                                                               \
         u8 *st = (u8 *)state;                                                                                          \
@@ -492,6 +523,19 @@ int mpcx_aby3_msb_round_pre(mpcx_ctx *ctx, uint64_t *state, uint64_t n, uint64_t
     MPCX_LAUNCH_CHECK();
     return 0;
 }
+int mpcx_aby3_msb_round_pre_bits(mpcx_ctx *ctx, uint64_t *state, uint64_t n, uint64_t temp, uint32_t *bits_out) {
+    if (n == 0) return 0;
+    MPCX_TRY(msb_round_check(ctx, "mpcx_aby3_msb_round_pre_bits", state, bits_out, temp));
+    MsbIn in;
+    MPCX_TRY(msb_level_in(ctx, "mpcx_aby3_msb_round_pre_bits", state, n, temp, &in));
+    ProfScope ps(ctx, PROF_MSB);
+    u8 *bk0 = (u8 *)state + msb_backup_base(n), *bk1 = bk0 + msb_backup_stride(n);
+#define EXTRA , bk0, bk1
+    MSB_ROUND_LAUNCH_BITS(msb_round_pre_kernel, (u8 *)bits_out);
+#undef EXTRA
+    MPCX_LAUNCH_CHECK();
+    return 0;
+}
 int mpcx_aby3_msb_round_post(mpcx_ctx *ctx, uint64_t *state, uint64_t n, uint64_t temp, const int8_t *msg_in) {
     if (n == 0) return 0;
     MPCX_TRY(msb_round_check(ctx, "mpcx_aby3_msb_round_post", state, msg_in, temp));
@@ -505,19 +549,30 @@ int mpcx_aby3_msb_round_post(mpcx_ctx *ctx, uint64_t *state, uint64_t n, uint64_
     return 0;
 }
 #undef MSB_ROUND_LAUNCH
-int mpcx_aby3_msb_round_mid(mpcx_ctx *ctx, uint64_t *state, uint64_t n, uint64_t temp, const int8_t *msg_in,
-                            int8_t *msg_out) {
+#undef MSB_ROUND_LAUNCH_BITS
+// bits = 0: the messages are wire bytes; 1: bit strings (the _bits entry points)
+static int msb_round_mid_impl(mpcx_ctx *ctx, const char *who, uint64_t *state, uint64_t n, uint64_t temp, const int8_t *msg_in,
+                              int8_t *msg_out, int bits) {
     if (n == 0) return 0;
-    MPCX_TRY(msb_round_check(ctx, "mpcx_aby3_msb_round_mid", state, msg_in, temp));
-    MPCX_REQUIRE(temp != 1, "mpcx_aby3_msb_round_mid: temp = 1 is the last round (mpcx_aby3_msb_last)");
-    MPCX_REQUIRE(msg_out && ((uintptr_t)msg_out & 7) == 0, "mpcx_aby3_msb_round_mid: msg_out must be 8-byte aligned");
+    MPCX_TRY(msb_round_check(ctx, who, state, msg_in, temp));
+    MPCX_REQUIRE(temp != 1, "%s: temp = 1 is the last round (mpcx_aby3_msb_last)", who);
+    MPCX_REQUIRE(msg_out && ((uintptr_t)msg_out & 7) == 0, "%s: msg_out must be 8-byte aligned", who);
     const u32 T = (u32)temp;
     const u64 nbits = 2 * temp * n;
-    if (nbits < 4096) {
+    if (nbits < 4096 && !bits) {
         // A handful of lanes: the word-rounded arrays of level T and level T/4 may share bytes of the state, which
         // the one-pass kernel would write while other lanes still read them.  Two passes, as the separate calls do.
         MPCX_TRY(mpcx_aby3_msb_round_post(ctx, state, n, temp, msg_in));
         return mpcx_aby3_msb_round_pre(ctx, state, n, temp / 2, msg_out);
+    }
+    if (nbits < 4096) { // the same two passes on a bit string: expand it on the device, then the packed first half
+        void *ws;
+        MPCX_TRY(mpcx_ws(ctx, (nbits + 15) & ~15ull, &ws));
+        u8 *bytes = (u8 *)ws;
+        const u32 *w = (const u32 *)msg_in;
+        MPCX_TRY(ew_launch(ctx, nbits, [=] __device__(u64 t) { bytes[t] = (u8)((w[t >> 5] >> (t & 31)) & 1u); }));
+        MPCX_TRY(mpcx_aby3_msb_round_post(ctx, state, n, temp, (const i8 *)bytes));
+        return mpcx_aby3_msb_round_pre_bits(ctx, state, n, temp / 2, (u32 *)msg_out);
     }
     MsbIn in;
     MPCX_TRY(msb_level_in(ctx, "mpcx_aby3_msb_round_mid", state, n, temp, &in));
@@ -533,7 +588,14 @@ int mpcx_aby3_msb_round_mid(mpcx_ctx *ctx, uint64_t *state, uint64_t n, uint64_t
 #define MSB_MID(A16, FIRST)                                                                                            \
     hipLaunchKernelGGL((msb_round_mid_kernel<A16, FIRST>), grid, block, 0, ctx->stream, in.a[1], g1_words, half, shalf,   \
                        quarter, squarter, nbits, mi, mo)
-    if (a16 && T == 32)
+    if (bits) {
+        if (T == 32)
+            hipLaunchKernelGGL((msb_round_mid_kernel<true, true, true>), grid, block, 0, ctx->stream, in.a[1], g1_words, half,
+                               shalf, quarter, squarter, nbits, mi, mo);
+        else
+            hipLaunchKernelGGL((msb_round_mid_kernel<true, false, true>), grid, block, 0, ctx->stream, in.a[1], g1_words, half,
+                               shalf, quarter, squarter, nbits, mi, mo);
+    } else if (a16 && T == 32)
         MSB_MID(true, true);
     else if (a16)
         MSB_MID(true, false);
@@ -545,6 +607,14 @@ int mpcx_aby3_msb_round_mid(mpcx_ctx *ctx, uint64_t *state, uint64_t n, uint64_t
     MPCX_LAUNCH_CHECK();
     return 0;
 }
+int mpcx_aby3_msb_round_mid(mpcx_ctx *ctx, uint64_t *state, uint64_t n, uint64_t temp, const int8_t *msg_in,
+                            int8_t *msg_out) {
+    return msb_round_mid_impl(ctx, "mpcx_aby3_msb_round_mid", state, n, temp, msg_in, msg_out, 0);
+}
+int mpcx_aby3_msb_round_mid_bits(mpcx_ctx *ctx, uint64_t *state, uint64_t n, uint64_t temp, const uint32_t *bits_in,
+                                 uint32_t *bits_out) {
+    return msb_round_mid_impl(ctx, "mpcx_aby3_msb_round_mid_bits", state, n, temp, (const int8_t *)bits_in, (int8_t *)bits_out, 1);
+}
 int mpcx_aby3_msb_final(mpcx_ctx *ctx, const uint64_t *state, const int64_t *P0_in, const int64_t *P1_in, uint64_t n,
                         int8_t *Z0, int8_t *Z1) {
     MPCX_REQUIRE((state && P0_in && P1_in && Z0 && Z1) || n == 0, "mpcx_aby3_msb_final: NULL pointer");
@@ -554,6 +624,20 @@ int mpcx_aby3_msb_final(mpcx_ctx *ctx, const uint64_t *state, const int64_t *P0_
         Z0[i] = (i8)(((g0[i >> 3] >> (i & 7)) & 1) ^ ((u64)P0_in[i] >> 63));
         Z1[i] = (i8)(((g1[i >> 3] >> (i & 7)) & 1) ^ ((u64)P1_in[i] >> 63));
     });
+}
+int mpcx_aby3_msb_last_bits(mpcx_ctx *ctx, const uint64_t *state, uint64_t n, const uint32_t *bits_in, int8_t *Z0, int8_t *Z1) {
+    if (n == 0) return 0;
+    MPCX_REQUIRE(state && bits_in && Z0 && Z1, "mpcx_aby3_msb_last_bits: NULL pointer");
+    ctx->msb_inputs.erase(state);
+    const u8 *st = (const u8 *)state;
+    const u8 *g1_lvl1 = st + msb_base(n, 1) + msb_stride(n, 1), *g0_lvl0 = st + msb_base(n, 0);
+    ProfScope ps(ctx, PROF_MSB);
+    const u8 *bk0 = st + msb_backup_base(n), *bk1 = bk0 + msb_backup_stride(n);
+    const dim3 grid(grid_for(ceil_div(n, 8))), block(256);
+    hipLaunchKernelGGL((msb_last_kernel<false, true>), grid, block, 0, ctx->stream, g1_lvl1, g0_lvl0, (const u8 *)bits_in, bk0,
+                       bk1, n, (u8 *)Z0, (u8 *)Z1);
+    MPCX_LAUNCH_CHECK();
+    return 0;
 }
 int mpcx_aby3_msb_last(mpcx_ctx *ctx, const uint64_t *state, uint64_t n, const int8_t *msg_in, int8_t *Z0, int8_t *Z1) {
     if (n == 0) return 0;

@@ -417,6 +417,96 @@ int mpcx_d2h(mpcx_ctx *ctx, void *dst, const void *src, uint64_t bytes) {
     MPCX_HIP(hipStreamSynchronize(ctx->stream));
     return 0;
 }
+// ---- boolean messages across the link as bit strings.  The wire carries one byte per boolean (utils/util.hpp:
+// vecbool2string); the device keeps booleans as bits.  These two move the bits and make / read the bytes on the host, in
+// the copy threads that would otherwise only copy them: an eighth of the bytes cross the link.
+static void expand_bits(u8 *dst, const u8 *bits, u64 first_bit, u64 nbits) { // first_bit a multiple of 8
+    const u8 *b = bits + first_bit / 8;
+    u64 t = 0;
+    for (; t + 8 <= nbits; t += 8) {
+        // bit k of the byte to byte k: the spread product has bit k of byte k set where bit k is set
+        const u64 spread = ((u64)b[t >> 3] * 0x0101010101010101ull) & 0x8040201008040201ull;
+        const u64 bytes = ((spread + 0x7F7F7F7F7F7F7F7Full) >> 7) & 0x0101010101010101ull;
+        memcpy(dst + t, &bytes, 8);
+    }
+    for (; t < nbits; t++) dst[t] = (u8)((b[t >> 3] >> (t & 7)) & 1u);
+}
+static void pack_bits(u8 *bits, const u8 *src, u64 nbits) { // writes ceil(nbits / 8) bytes, unused bits zero
+    u64 t = 0;
+    for (; t + 8 <= nbits; t += 8) {
+        u64 w;
+        memcpy(&w, src + t, 8);
+        bits[t >> 3] = (u8)(((w & 0x0101010101010101ull) * 0x0102040810204080ull) >> 56); // bit 0 of byte k to bit k
+    }
+    if (t < nbits) {
+        u8 v = 0;
+        for (u64 k = t; k < nbits; k++) v |= (u8)((src[k] & 1u) << (k & 7));
+        bits[t >> 3] = v;
+    }
+}
+int mpcx_d2h_bits(mpcx_ctx *ctx, void *dst_bytes, const void *src_bits, uint64_t nbits) {
+    MPCX_REQUIRE(ctx, "mpcx_d2h_bits: the context is NULL (already shut down?)");
+    if (!nbits) return 0;
+    MPCX_REQUIRE(dst_bytes && src_bits, "mpcx_d2h_bits: NULL pointer");
+    CopyTimer timer(1, (nbits + 7) / 8);
+    MPCX_TRY(stage_setup(ctx));
+    const u64 packed = (nbits + 7) / 8, chunks = (packed + kStageChunk - 1) / kStageChunk;
+    auto issue = [&](u64 k) -> int {
+        const u64 off = k * kStageChunk, len = packed - off < kStageChunk ? packed - off : kStageChunk;
+        MPCX_HIP(hipMemcpyAsync(ctx->stage[k & 1], (const char *)src_bits + off, len, hipMemcpyDeviceToHost, ctx->stream));
+        MPCX_HIP(hipEventRecord(ctx->stage_ev[k & 1], ctx->stream));
+        return 0;
+    };
+    MPCX_TRY(issue(0));
+    for (u64 k = 0; k < chunks; k++) {
+        if (k + 1 < chunks) MPCX_TRY(issue(k + 1)); // into the other buffer, emptied in the previous iteration
+        MPCX_HIP(hipEventSynchronize(ctx->stage_ev[k & 1]));
+        const u64 bit0 = k * kStageChunk * 8, bits_here = nbits - bit0 < kStageChunk * 8 ? nbits - bit0 : kStageChunk * 8;
+        const u8 *stage = (const u8 *)ctx->stage[k & 1];
+        u8 *out = (u8 *)dst_bytes + bit0;
+        const u64 piece_bits = 1ull << 20; // a megabyte of output per piece at least
+        u64 pieces = bits_here / piece_bits;
+        const u64 most = copy_pool().threads + 1;
+        pieces = pieces < 1 ? 1 : pieces > most ? most : pieces;
+        const u64 per = ((bits_here + pieces - 1) / pieces + 63) & ~63ull;
+        pool_run(pieces, [=](u64 p) {
+            const u64 lo = p * per;
+            if (lo < bits_here) expand_bits(out + lo, stage, lo, bits_here - lo < per ? bits_here - lo : per);
+        });
+    }
+    return 0;
+}
+int mpcx_h2d_bits(mpcx_ctx *ctx, void *dst_bits, const void *src_bytes, uint64_t nbits) {
+    MPCX_REQUIRE(ctx, "mpcx_h2d_bits: the context is NULL (already shut down?)");
+    if (!nbits) return 0;
+    MPCX_REQUIRE(dst_bits && src_bytes, "mpcx_h2d_bits: NULL pointer");
+    CopyTimer timer(0, (nbits + 7) / 8);
+    MPCX_TRY(stage_setup(ctx));
+    // whole 32-bit words reach the device (the kernels read the string word by word), the bits beyond it zero
+    const u64 packed = ((nbits + 31) / 32) * 4;
+    u64 k = 0;
+    for (u64 off = 0; off < packed; off += kStageChunk, k++) {
+        const u64 len = packed - off < kStageChunk ? packed - off : kStageChunk;
+        if (k >= 2) MPCX_HIP(hipEventSynchronize(ctx->stage_ev[k & 1])); // its previous chunk has left the buffer
+        u8 *stage = (u8 *)ctx->stage[k & 1];
+        const u64 bit0 = off * 8, bits_here = nbits - bit0 < len * 8 ? nbits - bit0 : len * 8;
+        const u8 *in = (const u8 *)src_bytes + bit0;
+        const u64 piece_bits = 1ull << 20;
+        u64 pieces = bits_here / piece_bits;
+        const u64 most = copy_pool().threads + 1;
+        pieces = pieces < 1 ? 1 : pieces > most ? most : pieces;
+        const u64 per = ((bits_here + pieces - 1) / pieces + 63) & ~63ull;
+        pool_run(pieces, [=](u64 p) {
+            const u64 lo = p * per;
+            if (lo < bits_here) pack_bits(stage + lo / 8, in + lo, bits_here - lo < per ? bits_here - lo : per);
+        });
+        for (u64 b = (bits_here + 7) / 8; b < len; b++) stage[b] = 0; // the rest of the last word
+        MPCX_HIP(hipMemcpyAsync((char *)dst_bits + off, stage, len, hipMemcpyHostToDevice, ctx->stream));
+        MPCX_HIP(hipEventRecord(ctx->stage_ev[k & 1], ctx->stream));
+    }
+    MPCX_HIP(hipStreamSynchronize(ctx->stream)); // the staging buffers are free again when the call returns
+    return 0;
+}
 int mpcx_host_copy(void *dst, const void *src, uint64_t bytes) {
     CopyTimer timer(2, bytes);
     if (bytes) mpcx_parallel_memcpy(dst, src, bytes);

@@ -419,6 +419,85 @@ def test_aby3_msb_messages_at_8_byte_alignment(gpu, orc, n, monkeypatch):
             assert np.array_equal(res[0][1][j][i], res[1][1][j][i])
 
 
+@pytest.mark.parametrize("nbits", [1, 7, 8, 63, 64, 65, 4099, (1 << 20) + 13, (36 << 20) + 77])
+def test_boolean_payloads_cross_the_link_as_bits(gpu, nbits):
+    """mpcx_h2d_bits / mpcx_d2h_bits: bytes of 0 / 1 on the host <-> a bit string on the device (several staging chunks
+    for the largest), only bit 0 of a host byte counts, the bits of the last word beyond the payload arrive as zero."""
+    import ctypes
+    ctx = gpu.ctx
+    rng = np.random.default_rng(nbits)
+    src = rng.integers(0, 256, nbits, dtype=np.uint8)  # wild bytes: bit 0 is the boolean
+    words = (nbits + 31) // 32
+    dev = ctx.to_device(np.full(words, 0xFFFFFFFF, dtype=np.uint32))
+    ctx._call("mpcx_h2d_bits", ctypes.c_void_p(dev.ptr), ctypes.c_void_p(src.ctypes.data), ctypes.c_uint64(nbits))
+    got_words = dev.to_host()
+    want_bits = np.zeros(words * 32, dtype=np.uint8)
+    want_bits[:nbits] = src & 1
+    assert np.array_equal(got_words, np.packbits(want_bits, bitorder="little").view(np.uint32))
+    back = np.full(nbits + 3, 7, dtype=np.uint8)
+    ctx._call("mpcx_d2h_bits", ctypes.c_void_p(back.ctypes.data), ctypes.c_void_p(dev.ptr), ctypes.c_uint64(nbits))
+    assert np.array_equal(back[:nbits], src & 1) and np.all(back[nbits:] == 7)
+
+
+@pytest.mark.parametrize("n", [1, 5, 63, 64, 65, 1000, 4097, (1 << 18) + 4099])
+def test_aby3_msb_segments_on_bit_strings(gpu, n):
+    """The msb segments with messages kept as bit strings on the device (round_pre_bits / round_mid_bits / last_bits,
+    bytes made and read on the host) against the byte forms: every outgoing message, the tree state they leave behind
+    and both result vectors are identical, whatever bytes come in."""
+    import ctypes
+    ctx = gpu.ctx
+    rng = np.random.default_rng(n)
+    G0, G1, P0, P1 = (ctx.to_device(rnd(rng, n)) for _ in range(4))
+    incoming = {t: rng.integers(0, 2, 2 * t * n, dtype=np.int8) for t in (32, 16, 8, 4, 2, 1)}
+    U64, P = ctypes.c_uint64, lambda d: ctypes.c_void_p(d.ptr)
+
+    def run(bits):
+        state = ctx.empty(np.uint64, 6 * n)
+        ctx.call("aby3_msb_begin", G0, G1, P0, P1, n, state)
+        sent = []
+        words = lambda nb: (nb + 31) // 32
+        out_b, in_b = ctx.empty(np.int8, 64 * n), ctx.empty(np.int8, 64 * n)
+        out_w, in_w = ctx.empty(np.uint32, words(64 * n)), ctx.empty(np.uint32, words(64 * n))
+        Z0, Z1 = ctx.empty(np.int8, n), ctx.empty(np.int8, n)
+
+        def fetch(nb):
+            if not bits:
+                return out_b.to_host()[:nb].copy()
+            host = np.zeros(nb, dtype=np.int8)
+            ctx._call("mpcx_d2h_bits", ctypes.c_void_p(host.ctypes.data), P(out_w), U64(nb))
+            return host
+
+        def feed(msg):
+            if not bits:
+                ctx._call("mpcx_h2d", P(in_b), ctypes.c_void_p(msg.ctypes.data), U64(msg.size))
+            else:
+                ctx._call("mpcx_h2d_bits", P(in_w), ctypes.c_void_p(msg.ctypes.data), U64(msg.size))
+
+        if bits:
+            ctx._call("mpcx_aby3_msb_round_pre_bits", P(state), U64(n), U64(32), P(out_w))
+        else:
+            ctx.call("aby3_msb_round_pre", state, n, 32, out_b)
+        sent.append(fetch(64 * n))
+        for t in (32, 16, 8, 4, 2):
+            feed(incoming[t])
+            if bits:
+                ctx._call("mpcx_aby3_msb_round_mid_bits", P(state), U64(n), U64(t), P(in_w), P(out_w))
+            else:
+                ctx.call("aby3_msb_round_mid", state, n, t, in_b, out_b)
+            sent.append(fetch(t * n))
+        feed(incoming[1])
+        if bits:
+            ctx._call("mpcx_aby3_msb_last_bits", P(state), U64(n), P(in_w), P(Z0), P(Z1))
+        else:
+            ctx.call("aby3_msb_last", state, n, in_b, Z0, Z1)
+        return sent, Z0.to_host(), Z1.to_host()
+
+    want, got = run(False), run(True)
+    for k, (a, b) in enumerate(zip(want[0], got[0])):
+        assert np.array_equal(a, b), f"message {k} differs"
+    assert np.array_equal(want[1], got[1]) and np.array_equal(want[2], got[2])
+
+
 def test_profile_collects_per_family_and_select_restricts_it(gpu):
     """mpcx_profile / mpcx_profile_select / mpcx_profile_read: launches are counted per kernel family, a selected
     family is the only one that records, and the kernel-name query names the GEMM kernel a shape runs in."""
