@@ -125,6 +125,44 @@ void add_prepare_group(ABY3Engine &e, const array<VecI64, 2> &Xj, array<VecI64, 
     string2vecI64(e.message_recv[pe.next], Gj[1]);
 }
 
+// The messages of the carry tree are booleans, one byte each on the wire (vecbool2string).  Between device and host
+// they travel as bit strings -- an eighth of the bytes over the link -- and the bytes are made and read by the host's
+// copy threads (mpcx_d2h_bits / mpcx_h2d_bits); MPCX_MSB_WIRE=bytes moves the bytes themselves, for comparison.  The
+// device buffers (64 bytes per element) hold either form.
+bool msb_as_bits() {
+    static const bool on = [] {
+        const char *e = getenv("MPCX_MSB_WIRE");
+        return !(e && strcmp(e, "bytes") == 0);
+    }();
+    return on;
+}
+void msb_first(mpcx_ctx *ctx, uint64_t *state, size_t cnt, int8_t *msg_out) {
+    if (msb_as_bits())
+        GPU_OK(ctx, mpcx_aby3_msb_round_pre_bits(ctx, state, cnt, 32, (uint32_t *)msg_out));
+    else
+        GPU_OK(ctx, mpcx_aby3_msb_round_pre(ctx, state, cnt, 32, msg_out));
+}
+void msb_next(mpcx_ctx *ctx, uint64_t *state, size_t cnt, size_t temp, const int8_t *msg_in, int8_t *msg_out) {
+    if (msb_as_bits())
+        GPU_OK(ctx, mpcx_aby3_msb_round_mid_bits(ctx, state, cnt, temp, (const uint32_t *)msg_in, (uint32_t *)msg_out));
+    else
+        GPU_OK(ctx, mpcx_aby3_msb_round_mid(ctx, state, cnt, temp, msg_in, msg_out));
+}
+void msb_end(mpcx_ctx *ctx, const uint64_t *state, size_t cnt, const int8_t *msg_in, int8_t *z0, int8_t *z1) {
+    if (msb_as_bits())
+        GPU_OK(ctx, mpcx_aby3_msb_last_bits(ctx, state, cnt, (const uint32_t *)msg_in, z0, z1));
+    else
+        GPU_OK(ctx, mpcx_aby3_msb_last(ctx, state, cnt, msg_in, z0, z1));
+}
+void msb_msg_down(mpcx_ctx *ctx, char *host, const int8_t *dev, size_t booleans) {
+    if (!booleans) return;
+    GPU_OK(ctx, msb_as_bits() ? mpcx_d2h_bits(ctx, host, dev, booleans) : mpcx_d2h(ctx, host, dev, booleans));
+}
+void msb_msg_up(mpcx_ctx *ctx, int8_t *dev, const char *host, size_t booleans) {
+    if (!booleans) return;
+    GPU_OK(ctx, msb_as_bits() ? mpcx_h2d_bits(ctx, dev, host, booleans) : mpcx_h2d(ctx, dev, host, booleans));
+}
+
 void msb_group(ABY3Engine &e, const array<VecI64, 2> &Gj, const array<VecI64, 2> &Pj, array<vecbool, 2> &Zj) {
     const Peers pe(e.party_id);
     const size_t n = Gj[0].size(), G = mpcx_group_size(e.group);
@@ -145,8 +183,8 @@ void msb_group(ABY3Engine &e, const array<VecI64, 2> &Gj, const array<VecI64, 2>
         z0[m].reset(new Dev<int8_t>(ctx, cnt));
         z1[m].reset(new Dev<int8_t>(ctx, cnt));
         GPU_OK(ctx, mpcx_aby3_msb_begin(ctx, *g0[m], *g1[m], *p0[m], *p1[m], cnt, *state[m]));
-        GPU_OK(ctx, mpcx_aby3_msb_round_pre(ctx, *state[m], cnt, 32, *msg_out[m]));
-        if (cnt) msg_out[m]->down(&out[64 * i0], 64 * cnt);
+        msb_first(ctx, *state[m], cnt, *msg_out[m]);
+        msb_msg_down(ctx, &out[64 * i0], *msg_out[m], 64 * cnt);
     });
     Zj[0].resize(n);
     Zj[1].resize(n);
@@ -159,12 +197,12 @@ void msb_group(ABY3Engine &e, const array<VecI64, 2> &Gj, const array<VecI64, 2>
         if (temp != 1) out.resize(per / 2 * n); // the next message is written in place, slice by slice
         mpcgpu::group_for_each(e.group, n, RANGE_GRANULE, [&](mpcx_ctx *ctx, int m, uint64_t i0, uint64_t cnt) {
             if (!cnt) return;
-            GPU_OK(ctx, mpcx_h2d(ctx, msg_in[m]->p, in.data() + per * i0, per * cnt));
+            msb_msg_up(ctx, *msg_in[m], in.data() + per * i0, per * cnt);
             if (temp != 1) {
-                GPU_OK(ctx, mpcx_aby3_msb_round_mid(ctx, *state[m], cnt, temp, *msg_in[m], *msg_out[m]));
-                msg_out[m]->down(&out[per / 2 * i0], per / 2 * cnt);
+                msb_next(ctx, *state[m], cnt, temp, *msg_in[m], *msg_out[m]);
+                msb_msg_down(ctx, &out[per / 2 * i0], *msg_out[m], per / 2 * cnt);
             } else {
-                GPU_OK(ctx, mpcx_aby3_msb_last(ctx, *state[m], cnt, *msg_in[m], *z0[m], *z1[m]));
+                msb_end(ctx, *state[m], cnt, *msg_in[m], *z0[m], *z1[m]);
                 z0[m]->down(Zj[0].data() + i0, cnt);
                 z1[m]->down(Zj[1].data() + i0, cnt);
             }
@@ -562,19 +600,19 @@ void ABY3Engine::msb(const array<VecI64, 2> &Gj, const array<VecI64, 2> &Pj, arr
     GPU_OK(gpu, mpcx_aby3_msb_begin(gpu, g0, g1, p0, p1, n, state));
     // one device call per local segment: the first message, then for every received message the next one, then Z
     Dev<int8_t> msg_in(gpu, 64 * n), msg_out(gpu, 64 * n), z0(gpu, n), z1(gpu, n);
-    GPU_OK(gpu, mpcx_aby3_msb_round_pre(gpu, state, n, 32, msg_out));
+    msb_first(gpu, state, n, msg_out);
     for (size_t temp = 32; temp != 0; temp /= 2) {
         const size_t bytes = 2 * temp * n;
         message_send[pe.next].clear();
         message_send[pe.prev].resize(bytes);
-        if (bytes) msg_out.down(&message_send[pe.prev][0], bytes);
+        if (bytes) msb_msg_down(gpu, &message_send[pe.prev][0], msg_out, bytes);
         messenger->send_and_recv(message_send, message_recv);
         MSG_CHECK(message_recv[pe.next].size() == bytes);
-        upload_string(msg_in, message_recv[pe.next]);
+        msb_msg_up(gpu, msg_in, message_recv[pe.next].data(), bytes);
         if (temp != 1)
-            GPU_OK(gpu, mpcx_aby3_msb_round_mid(gpu, state, n, temp, msg_in, msg_out));
+            msb_next(gpu, state, n, temp, msg_in, msg_out);
         else
-            GPU_OK(gpu, mpcx_aby3_msb_last(gpu, state, n, msg_in, z0, z1));
+            msb_end(gpu, state, n, msg_in, z0, z1);
     }
     Zj[0].resize(n);
     Zj[1].resize(n);
@@ -733,8 +771,8 @@ void ABY3Engine::relu(const VecPair &Xj, VecPair &Rj) {
         fresh(z0[m], ctx, cnt);
         fresh(z1[m], ctx, cnt);
         GPU_OK(ctx, mpcx_aby3_msb_begin(ctx, *g0[m], *g1[m], *p0[m], *p1[m], cnt, *state[m]));
-        GPU_OK(ctx, mpcx_aby3_msb_round_pre(ctx, *state[m], cnt, 32, *msg_out[m]));
-        if (cnt) msg_out[m]->down(&out[64 * i0], 64 * cnt);
+        msb_first(ctx, *state[m], cnt, *msg_out[m]);
+        msb_msg_down(ctx, &out[64 * i0], *msg_out[m], 64 * cnt);
     });
     for (size_t temp = 32; temp != 0; temp /= 2) {
         const size_t per = 2 * temp; // message bytes per element of this round
@@ -745,12 +783,12 @@ void ABY3Engine::relu(const VecPair &Xj, VecPair &Rj) {
         if (temp != 1) out.resize(per / 2 * n); // the next message is written in place, slice by slice
         mpcgpu::run(*this, n, [&](mpcx_ctx *ctx, int m, uint64_t i0, uint64_t cnt) {
             if (!cnt) return;
-            GPU_OK(ctx, mpcx_h2d(ctx, msg_in[m]->p, in.data() + per * i0, per * cnt));
+            msb_msg_up(ctx, *msg_in[m], in.data() + per * i0, per * cnt);
             if (temp != 1) {
-                GPU_OK(ctx, mpcx_aby3_msb_round_mid(ctx, *state[m], cnt, temp, *msg_in[m], *msg_out[m]));
-                msg_out[m]->down(&out[per / 2 * i0], per / 2 * cnt);
+                msb_next(ctx, *state[m], cnt, temp, *msg_in[m], *msg_out[m]);
+                msb_msg_down(ctx, &out[per / 2 * i0], *msg_out[m], per / 2 * cnt);
             } else {
-                GPU_OK(ctx, mpcx_aby3_msb_last(ctx, *state[m], cnt, *msg_in[m], *z0[m], *z1[m]));
+                msb_end(ctx, *state[m], cnt, *msg_in[m], *z0[m], *z1[m]);
             }
         });
     }
