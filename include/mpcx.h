@@ -57,6 +57,12 @@ int mpcx_d2h(mpcx_ctx *ctx, void *dst, const void *src, uint64_t bytes);
  * h2d_bits takes bit 0 of every host byte and writes whole 32-bit words, the bits beyond nbits zero. */
 int mpcx_d2h_bits(mpcx_ctx *ctx, void *dst_bytes, const void *src_bits, uint64_t nbits);
 int mpcx_h2d_bits(mpcx_ctx *ctx, void *dst_bits, const void *src_bytes, uint64_t nbits);
+/* `count` uint16 values between a device array and (possibly unaligned) host memory, e.g. the Z_67 shares of
+ * privateCompare (SecurennEngine.cpp:559-589: uint16 on the wire, values below 67).  Same result as mpcx_d2h / mpcx_h2d
+ * of 2 * count bytes; when no value exceeds 255 only count bytes cross the host link (narrowed / widened by a kernel on
+ * the device and by the copy threads on the host), otherwise the array goes as it is. */
+int mpcx_d2h_u16(mpcx_ctx *ctx, void *dst, const void *src, uint64_t count);
+int mpcx_h2d_u16(mpcx_ctx *ctx, void *dst, const void *src, uint64_t count);
 int mpcx_d2d(mpcx_ctx *ctx, void *dst, const void *src, uint64_t bytes);
 /* mpcx_h2d / mpcx_d2h return when the copy is complete; host memory may be pageable (the std::string payloads of
  * VirtuleMessenger::send_and_recv, utils/VirtuleMessenger.hpp:14).  Transfers of 4 MiB and more are pipelined through

@@ -507,6 +507,170 @@ int mpcx_h2d_bits(mpcx_ctx *ctx, void *dst_bits, const void *src_bytes, uint64_t
     MPCX_HIP(hipStreamSynchronize(ctx->stream)); // the staging buffers are free again when the call returns
     return 0;
 }
+} // extern "C"
+// ---- 16-bit payloads whose values fit a byte.  The Z_67 shares of privateCompare are uint16 on the wire
+// (SecurennEngine.cpp:559-589) and never exceed 66: such arrays cross the link as bytes -- narrowed by a kernel and
+// widened by the copy threads on the way down, narrowed by the copy threads and widened by a kernel on the way up.
+// Nothing is assumed: the narrowing pass reports a value above 255, and the array then goes as it is.
+namespace {
+__device__ inline u32 narrow2(u32 w) { return (w & 0xFFu) | ((w >> 8) & 0xFF00u); } // two uint16 -> two bytes
+__global__ __launch_bounds__(256) void narrow_u16_kernel(const u16 *__restrict__ src, u64 count, u8 *__restrict__ dst,
+                                                         u32 *__restrict__ wide, int vec) {
+    u32 high = 0;
+    if (vec) { // src 16-byte aligned: eight values per lane
+        const u64 groups = count / 8;
+        for (u64 g = (u64)blockIdx.x * 256 + threadIdx.x; g < groups; g += (u64)gridDim.x * 256) {
+            const uint4 v = ((const uint4 *)src)[g];
+            high |= (v.x | v.y | v.z | v.w) & 0xFF00FF00u;
+            ((uint2 *)dst)[g] = make_uint2(narrow2(v.x) | narrow2(v.y) << 16, narrow2(v.z) | narrow2(v.w) << 16);
+        }
+        for (u64 i = groups * 8 + (u64)blockIdx.x * 256 + threadIdx.x; i < count; i += (u64)gridDim.x * 256) {
+            high |= src[i] & 0xFF00u;
+            dst[i] = (u8)src[i];
+        }
+    } else {
+        for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < count; i += (u64)gridDim.x * 256) {
+            high |= src[i] & 0xFF00u;
+            dst[i] = (u8)src[i];
+        }
+    }
+    if (high) atomicOr(wide, 1u);
+}
+__global__ __launch_bounds__(256) void widen_u8_kernel(const u8 *__restrict__ src, u64 count, u16 *__restrict__ dst, int vec) {
+    if (vec) { // dst 16-byte aligned
+        const u64 groups = count / 8;
+        for (u64 g = (u64)blockIdx.x * 256 + threadIdx.x; g < groups; g += (u64)gridDim.x * 256) {
+            const uint2 v = ((const uint2 *)src)[g];
+            auto w = [](u32 b) { return (b & 0xFFu) | ((b & 0xFF00u) << 8); };
+            ((uint4 *)dst)[g] = make_uint4(w(v.x), w(v.x >> 16), w(v.y), w(v.y >> 16));
+        }
+        for (u64 i = groups * 8 + (u64)blockIdx.x * 256 + threadIdx.x; i < count; i += (u64)gridDim.x * 256) dst[i] = src[i];
+    } else {
+        for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < count; i += (u64)gridDim.x * 256) dst[i] = src[i];
+    }
+}
+bool narrow_u16_payloads() { // MPCX_U16_WIRE=wide: 16-bit arrays always cross the link as they are (comparison)
+    static const bool on = [] {
+        const char *e = getenv("MPCX_U16_WIRE");
+        return !(e && strcmp(e, "wide") == 0);
+    }();
+    return on;
+}
+u32 grid_1d(u64 items) {
+    u64 b = (items + 255) / 256;
+    return (u32)(b < 1 ? 1 : b > 65536 ? 65536 : b);
+}
+// host side, on possibly unaligned arrays
+void widen_host(u8 *dst16, const u8 *src8, u64 count) {
+    for (u64 i = 0; i < count; i++) {
+        const u16 v = src8[i];
+        memcpy(dst16 + 2 * i, &v, 2);
+    }
+}
+u32 narrow_host(u8 *dst8, const u8 *src16, u64 count) { // returns the OR of the high bytes
+    u32 high = 0;
+    for (u64 i = 0; i < count; i++) {
+        u16 v;
+        memcpy(&v, src16 + 2 * i, 2);
+        high |= v & 0xFF00u;
+        dst8[i] = (u8)v;
+    }
+    return high;
+}
+const u64 kNarrowHeader = 256; // the device buffer starts with the flag word, the bytes follow 256 bytes in
+} // namespace
+extern "C" {
+int mpcx_d2h_u16(mpcx_ctx *ctx, void *dst, const void *src, uint64_t count) {
+    MPCX_REQUIRE(ctx, "mpcx_d2h_u16: the context is NULL (already shut down?)");
+    if (!count) return 0;
+    MPCX_REQUIRE(dst && src, "mpcx_d2h_u16: NULL pointer");
+    if (2 * count < kStageMin || !staged_copies() || !narrow_u16_payloads()) return mpcx_d2h(ctx, dst, src, 2 * count);
+    MPCX_TRY(stage_setup(ctx));
+    void *tmp = nullptr;
+    MPCX_TRY(mpcx_malloc(ctx, kNarrowHeader + count, &tmp));
+    auto fail = [&](int rc) {
+        (void)mpcx_free(ctx, tmp);
+        return rc;
+    };
+    if (hipMemsetAsync(tmp, 0, 4, ctx->stream) != hipSuccess) return fail(1);
+    hipLaunchKernelGGL(narrow_u16_kernel, dim3(grid_1d((count + 7) / 8)), dim3(256), 0, ctx->stream, (const u16 *)src, count,
+                       (u8 *)tmp + kNarrowHeader, (u32 *)tmp, ((uintptr_t)src & 15) == 0 ? 1 : 0);
+    CopyTimer timer(1, count);
+    const u64 total = kNarrowHeader + count, chunks = (total + kStageChunk - 1) / kStageChunk;
+    auto issue = [&](u64 k) -> int {
+        const u64 off = k * kStageChunk, len = total - off < kStageChunk ? total - off : kStageChunk;
+        MPCX_HIP(hipMemcpyAsync(ctx->stage[k & 1], (const char *)tmp + off, len, hipMemcpyDeviceToHost, ctx->stream));
+        MPCX_HIP(hipEventRecord(ctx->stage_ev[k & 1], ctx->stream));
+        return 0;
+    };
+    if (issue(0)) return fail(1);
+    for (u64 k = 0; k < chunks; k++) {
+        if (k + 1 < chunks && issue(k + 1)) return fail(1);
+        if (hipEventSynchronize(ctx->stage_ev[k & 1]) != hipSuccess) return fail(1);
+        if (k == 0 && *(const u32 *)ctx->stage[0] != 0) { // a value above 255: the array goes as it is
+            (void)hipStreamSynchronize(ctx->stream);       // (the next chunk may be on its way into the other buffer)
+            (void)mpcx_free(ctx, tmp);
+            return mpcx_d2h(ctx, dst, src, 2 * count);
+        }
+        const u64 off = k * kStageChunk, len = total - off < kStageChunk ? total - off : kStageChunk;
+        const u64 skip = k == 0 ? kNarrowHeader : 0;          // header bytes at the front of this chunk
+        const u64 first = off + skip - kNarrowHeader, here = len - skip; // values [first, first + here)
+        const u8 *stage = (const u8 *)ctx->stage[k & 1] + skip;
+        u8 *out = (u8 *)dst + 2 * first;
+        u64 pieces = here >> 19; // half a megabyte of bytes (a megabyte of output) per piece at least
+        const u64 most = copy_pool().threads + 1;
+        pieces = pieces < 1 ? 1 : pieces > most ? most : pieces;
+        const u64 per = (here + pieces - 1) / pieces;
+        pool_run(pieces, [=](u64 p) {
+            const u64 lo = p * per;
+            if (lo < here) widen_host(out + 2 * lo, stage + lo, here - lo < per ? here - lo : per);
+        });
+    }
+    return fail(0);
+}
+int mpcx_h2d_u16(mpcx_ctx *ctx, void *dst, const void *src, uint64_t count) {
+    MPCX_REQUIRE(ctx, "mpcx_h2d_u16: the context is NULL (already shut down?)");
+    if (!count) return 0;
+    MPCX_REQUIRE(dst && src, "mpcx_h2d_u16: NULL pointer");
+    if (2 * count < kStageMin || !staged_copies() || !narrow_u16_payloads()) return mpcx_h2d(ctx, dst, src, 2 * count);
+    MPCX_TRY(stage_setup(ctx));
+    void *tmp = nullptr;
+    MPCX_TRY(mpcx_malloc(ctx, count, &tmp));
+    CopyTimer timer(0, count);
+    auto high = std::make_shared<std::atomic<u32>>(0u);
+    u64 k = 0;
+    for (u64 off = 0; off < count; off += kStageChunk, k++) {
+        const u64 len = count - off < kStageChunk ? count - off : kStageChunk;
+        if (k >= 2 && hipEventSynchronize(ctx->stage_ev[k & 1]) != hipSuccess) break; // its previous chunk has left the buffer
+        u8 *stage = (u8 *)ctx->stage[k & 1];
+        const u8 *in = (const u8 *)src + 2 * off;
+        u64 pieces = len >> 19;
+        const u64 most = copy_pool().threads + 1;
+        pieces = pieces < 1 ? 1 : pieces > most ? most : pieces;
+        const u64 per = (len + pieces - 1) / pieces;
+        pool_run(pieces, [=](u64 p) {
+            const u64 lo = p * per;
+            if (lo < len) high->fetch_or(narrow_host(stage + lo, in + 2 * lo, len - lo < per ? len - lo : per));
+        });
+        if (high->load()) break;
+        if (hipMemcpyAsync((char *)tmp + off, stage, len, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+            hipEventRecord(ctx->stage_ev[k & 1], ctx->stream) != hipSuccess) {
+            high->store(0xFFFFFFFFu); // treated like a wide value: the plain path reports the error if it persists
+            break;
+        }
+    }
+    if (high->load()) { // a value above 255 (or a copy that would not start): the array goes as it is
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)mpcx_free(ctx, tmp);
+        return mpcx_h2d(ctx, dst, src, 2 * count);
+    }
+    hipLaunchKernelGGL(widen_u8_kernel, dim3(grid_1d((count + 7) / 8)), dim3(256), 0, ctx->stream, (const u8 *)tmp, count,
+                       (u16 *)dst, ((uintptr_t)dst & 15) == 0 ? 1 : 0);
+    const hipError_t e = hipStreamSynchronize(ctx->stream); // the staging buffers and tmp are free again
+    (void)mpcx_free(ctx, tmp);
+    MPCX_HIP(e);
+    return 0;
+}
 int mpcx_host_copy(void *dst, const void *src, uint64_t bytes) {
     CopyTimer timer(2, bytes);
     if (bytes) mpcx_parallel_memcpy(dst, src, bytes);

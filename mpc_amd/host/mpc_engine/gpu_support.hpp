@@ -124,9 +124,19 @@ template <class T> class Dev {
     Dev(const Dev &) = delete;
     Dev &operator=(const Dev &) = delete;
     ~Dev() { mpcx_free(ctx, p); }
-    void up(const void *host, size_t count) { GPU_OK(ctx, mpcx_h2d(ctx, p, host, count * sizeof(T))); }
+    // 16-bit arrays are the Z_67 shares of privateCompare (values below 67): the library moves such an array over the
+    // link as bytes when its values allow it, and as it is otherwise
+    void up(const void *host, size_t count) {
+        if (sizeof(T) == 2)
+            GPU_OK(ctx, mpcx_h2d_u16(ctx, p, host, count));
+        else
+            GPU_OK(ctx, mpcx_h2d(ctx, p, host, count * sizeof(T)));
+    }
     void down(void *host, size_t count, size_t first = 0) const {
-        GPU_OK(ctx, mpcx_d2h(ctx, host, p + first, count * sizeof(T)));
+        if (sizeof(T) == 2)
+            GPU_OK(ctx, mpcx_d2h_u16(ctx, host, p + first, count));
+        else
+            GPU_OK(ctx, mpcx_d2h(ctx, host, p + first, count * sizeof(T)));
     }
     // the whole buffer as a wire payload
     void to_string(std::string &s) const {
@@ -148,7 +158,11 @@ template <class T> inline void upload_string_at(Dev<T> &d, size_t dev_first, con
                 d.n);
         abort();
     }
-    if (bytes) GPU_OK(d.ctx, mpcx_h2d(d.ctx, d.p + dev_first, s.data() + byte_off, bytes));
+    if (!bytes) return;
+    if (sizeof(T) == 2 && bytes % 2 == 0)
+        GPU_OK(d.ctx, mpcx_h2d_u16(d.ctx, d.p + dev_first, s.data() + byte_off, bytes / 2));
+    else
+        GPU_OK(d.ctx, mpcx_h2d(d.ctx, d.p + dev_first, s.data() + byte_off, bytes));
 }
 
 template <class T> inline void upload_string(Dev<T> &d, const std::string &s, size_t byte_off = 0, size_t bytes = (size_t)-1) {
@@ -161,7 +175,11 @@ template <class T> inline void upload_string(Dev<T> &d, const std::string &s, si
         fprintf(stderr, "upload_string: %zu bytes do not fit a device buffer of %zu bytes\n", bytes, d.n * sizeof(T));
         abort();
     }
-    if (bytes) GPU_OK(d.ctx, mpcx_h2d(d.ctx, d.p, s.data() + byte_off, bytes));
+    if (!bytes) return;
+    if (sizeof(T) == 2 && bytes % 2 == 0)
+        GPU_OK(d.ctx, mpcx_h2d_u16(d.ctx, d.p, s.data() + byte_off, bytes / 2));
+    else
+        GPU_OK(d.ctx, mpcx_h2d(d.ctx, d.p, s.data() + byte_off, bytes));
 }
 
 // ---- protocols written over element ranges.  An engine E has a context `gpu` and a group `group` (NULL without

@@ -439,6 +439,33 @@ def test_boolean_payloads_cross_the_link_as_bits(gpu, nbits):
     assert np.array_equal(back[:nbits], src & 1) and np.all(back[nbits:] == 7)
 
 
+@pytest.mark.parametrize("count,wide_at", [(1000, None), ((2 << 20) + 3, None), ((9 << 20) + 5, None), ((9 << 20) + 5, 0),
+                                           ((9 << 20) + 5, (8 << 20) + 77), ((2 << 20) + 3, (2 << 20) + 2)])
+@pytest.mark.parametrize("skew", [0, 1])
+def test_16_bit_payloads_that_fit_a_byte(gpu, count, wide_at, skew):
+    """mpcx_h2d_u16 / mpcx_d2h_u16 return exactly what mpcx_h2d / mpcx_d2h of the same array return: arrays of Z_67-like
+    values go narrowed (several staging chunks for the largest), an array with one value above 255 anywhere goes as it
+    is; host memory at an odd address, device arrays that start one element into a buffer."""
+    import ctypes
+    ctx = gpu.ctx
+    rng = np.random.default_rng(count + skew)
+    vals = rng.integers(0, 67, count, dtype=np.uint16)
+    if wide_at is not None:
+        vals[wide_at] = 256 + 66
+    raw = np.zeros(2 * count + 8, dtype=np.uint8)
+    raw[skew:skew + 2 * count] = vals.view(np.uint8)  # the host array at an odd address when skew = 1
+    dev = ctx.to_device(np.full(count + 8, 0xABCD, dtype=np.uint16))
+    dptr = dev.ptr + 2 * skew  # ... and the device array one element into its buffer
+    ctx._call("mpcx_h2d_u16", ctypes.c_void_p(dptr), ctypes.c_void_p(raw.ctypes.data + skew), ctypes.c_uint64(count))
+    on_device = dev.to_host()
+    assert np.array_equal(on_device[skew:skew + count], vals)
+    assert np.all(on_device[:skew] == 0xABCD) and np.all(on_device[skew + count:] == 0xABCD)
+    back = np.full(2 * count + 8, 0x5A, dtype=np.uint8)
+    ctx._call("mpcx_d2h_u16", ctypes.c_void_p(back.ctypes.data + skew), ctypes.c_void_p(dptr), ctypes.c_uint64(count))
+    assert np.array_equal(back[skew:skew + 2 * count], vals.view(np.uint8))
+    assert np.all(back[:skew] == 0x5A) and np.all(back[skew + 2 * count:] == 0x5A)
+
+
 @pytest.mark.parametrize("n", [1, 5, 63, 64, 65, 1000, 4097, (1 << 18) + 4099])
 def test_aby3_msb_segments_on_bit_strings(gpu, n):
     """The msb segments with messages kept as bit strings on the device (round_pre_bits / round_mid_bits / last_bits,
