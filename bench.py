@@ -483,7 +483,18 @@ def bitwise_rates(ctx, torch, dev, log2n=24, rank=0, world=1, tables=None):
     out["aby3_relu_segments_ms"] = {k: round(v, 3) for k, v in sorted(seg.items(), key=lambda kv: -kv[1])}
     got = sum(torch.from_numpy(be.down(R[j])).to(dev) for j in range(3))
     assert torch.equal(got, torch.clamp(x, min=0)), "ABY3 ReLU chain: revealed values differ from max(x, 0)"
-    del R, got
+    # the same chain with the carry tree's messages kept as bit strings between the parties (the *_bits segments the C++
+    # engines run; they make the wire bytes on the host): 252 of the 380 B/elem and party are those messages
+    be.msb_bits = True
+    try:
+        aby3_relu()
+        dtb, Rb = _timed(torch, aby3_relu)
+    finally:
+        be.msb_bits = False
+    assert all(torch.equal(be.tensor(Rb[j]), be.tensor(R[j])) for j in range(3)), "ABY3 ReLU chain: bit-string messages change the shares"
+    rate("aby3_relu_bit_messages_elems_per_s", n, dtb)
+    out["aby3_relu_bit_messages_ms"] = round(dtb * 1e3, 3)
+    del R, Rb, got
 
     # ---- MyEngine ReLU chain (test/test_Myengine.cpp, benchmark/benchmark1.cpp:180-204): msb -> bit_inject -> subtract,
     # parties 0 / 1 and the dealer on this GPU; the drivers take whole vectors, so it runs on one rank only
@@ -833,6 +844,34 @@ def config5_slice(ctx, torch, dev):
                         "elems_per_s": rate, "ms_total": round(spent * 1e3, 2), "ms_per_range": per_batch,
                         "GBps": round(3 * 380.0 * rate / 1e9, 1), "hbm_frac": round(3 * 380.0 * rate / 1e9 / HBM_PEAK_GBS, 4),
                         "verified": "every range reveals max(x, 0)"}
+    # the same schedule with the carry tree's messages kept as bit strings between the parties (what the C++ engines'
+    # device side does; the wire bytes are then made on the host)
+    be.msb_bits = True
+    try:
+        spent_b = 0.0
+        for b in range(nt // n):
+            i0 = b * n
+            ctx.call("prg_fill_pop", 21, 0, i0, n, x)
+            xD = ctx.wrap(x, np.int64)
+
+            def chain_b():
+                w = pr.World(be, record=False, n_total=nt, i0=i0)
+                Xs = pr.aby3_share(w, xD, n)
+                Gs, Ps = pr.aby3_add_prepare(w, Xs)
+                Zb = pr.aby3_msb(w, Gs, Ps)
+                return pr.aby3_bit_inject(w, Xs, Zb, minuend=Xs)
+
+            if b == 0:
+                chain_b()
+            dt, R = _timed(torch, chain_b)
+            spent_b += dt
+            assert torch.equal(T(R[0][0]) + T(R[1][0]) + T(R[2][0]), torch.clamp(x, min=0)), \
+                f"config 5 ReLU chain with bit-string messages: range {b} does not reveal max(x, 0)"
+            del R
+    finally:
+        be.msb_bits = False
+    out["relu_2_28"]["bit_messages_elems_per_s"] = nt / spent_b
+    out["relu_2_28"]["bit_messages_ms_total"] = round(spent_b * 1e3, 2)
     return out
 
 

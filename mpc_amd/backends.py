@@ -362,7 +362,7 @@ class ResidentBackend(GpuBackend):
         super().__init__(ctx)
         self.torch, self.dev = torch, dev
         self._tdt = {np.dtype(np.int64): torch.int64, np.dtype(np.uint64): torch.int64, np.dtype(np.int8): torch.int8,
-                     np.dtype(np.uint16): torch.int16}
+                     np.dtype(np.uint16): torch.int16, np.dtype(np.uint32): torch.int32}
 
     def empty(self, dtype, n):
         t = self.torch.empty(max(int(n), 1), dtype=self._tdt[np.dtype(dtype)], device=self.dev)
@@ -422,6 +422,10 @@ class ResidentBackend(GpuBackend):
     def ring_gemm(self, *a, **k):
         raise NotImplementedError
 
+    # True: the carry tree's messages stay bit strings between the parties on this GPU (the *_bits segments, what the
+    # C++ engines run: they make the wire bytes on the host); False: wire bytes, one per boolean, in device memory
+    msb_bits = False
+
     class _Msb:
         def __init__(self, be, G0, G1, P0, P1):
             self.be, self.n, self.P0, self.P1 = be, G0.size, P0, P1
@@ -429,7 +433,14 @@ class ResidentBackend(GpuBackend):
             self.state = be.empty(np.uint64, 6 * self.n)
             be._run("aby3_msb_begin", G0, G1, P0, P1, self.n, self.state)
 
+        def _words(self, booleans):
+            return self.be.empty(np.uint32, (booleans + 31) // 32)
+
         def round_pre(self, temp):
+            if self.be.msb_bits and temp == 32:
+                msg = self._words(self.n * 64)
+                self.be._run("aby3_msb_round_pre_bits", self.state, self.n, temp, msg)
+                return msg
             msg = self.be.empty(np.int8, self.n * 2 * temp)
             self.be._run("aby3_msb_round_pre", self.state, self.n, temp, msg)
             return msg
@@ -443,13 +454,17 @@ class ResidentBackend(GpuBackend):
             return Z0, Z1
 
         def round_mid(self, temp, msg_in):
+            if self.be.msb_bits:
+                msg = self._words(self.n * temp)
+                self.be._run("aby3_msb_round_mid_bits", self.state, self.n, temp, msg_in, msg)
+                return msg
             msg = self.be.empty(np.int8, self.n * temp)
             self.be._run("aby3_msb_round_mid", self.state, self.n, temp, msg_in, msg)
             return msg
 
         def last(self, msg_in):
             Z0, Z1 = self.be.empty(np.int8, self.n), self.be.empty(np.int8, self.n)
-            self.be._run("aby3_msb_last", self.state, self.n, msg_in, Z0, Z1)
+            self.be._run("aby3_msb_last_bits" if self.be.msb_bits else "aby3_msb_last", self.state, self.n, msg_in, Z0, Z1)
             return Z0, Z1
 
     def aby3_msb_begin(self, G0, G1, P0, P1):
