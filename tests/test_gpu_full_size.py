@@ -44,6 +44,34 @@ def test_aby3_share_matmul_4096(env):
     assert not torch.equal(job.Z0[0], job.Z0[1]) and not torch.equal(job.Z0[0], job.Zplain[0])
 
 
+@pytest.mark.parametrize("n", [1, 77, 5000, 70001])
+def test_aby3_relu_chain_with_bit_string_messages(env, orc, n):
+    """The resident ReLU chain with the carry tree's messages handed from party to party as bit strings (the *_bits
+    segments) gives the oracle's shares, word for word: the representation of a message between two device-resident
+    parties changes nothing a party computes."""
+    import protocols as pr
+    ctx, torch, dev, be = env
+    rng = np.random.default_rng(n)
+    x = rng.integers(-2 ** 63, 2 ** 63, n, dtype=np.int64)
+
+    def chain(backend, xin):
+        w = pr.World(backend, record=False)
+        Xs = pr.aby3_share(w, xin, n)
+        Gs, Ps = pr.aby3_add_prepare(w, Xs)
+        Zb = pr.aby3_msb(w, Gs, Ps)
+        return pr.aby3_bit_inject(w, Xs, Zb, minuend=Xs)
+
+    want = chain(orc, x)
+    be.msb_bits = True
+    try:
+        got = chain(be, ctx.to_device(x))
+    finally:
+        be.msb_bits = False
+    for j in range(3):
+        for k in range(2):
+            assert np.array_equal(be.down(got[j][k]), want[j][k]), f"share {k} of party {j}"
+
+
 def uless(torch, a, b):
     """a < b for int64 tensors read as unsigned."""
     m = torch.iinfo(torch.int64).min
