@@ -400,6 +400,27 @@ def test_bad_shapes_are_rejected(gpu):
     b = np.zeros(4, dtype=np.int8)
     with pytest.raises(MpcxError, match="outside a vector"):  # elements [8, 12) of a 10-element vector
         gpu.aby3_bit_inject_p2_pre(b, b, KEY20, 0, KEY12, 0, rng=(10, 8))
+    # the additions: prepared operands, bit-string segments, narrowed copies
+    import ctypes
+    ctx = gpu.ctx
+    d = ctx.to_device(one)
+    P, U64, op = lambda x: ctypes.c_void_p(x.ptr), ctypes.c_uint64, ctypes.c_void_p()
+    with pytest.raises(MpcxError, match="empty shape"):
+        ctx._call("mpcx_aby3_operand_prepare", P(d), P(d), U64(0), U64(1), ctypes.c_int(0), ctypes.byref(op))
+    with pytest.raises(MpcxError, match="layout"):
+        ctx._call("mpcx_aby3_operand_prepare", P(d), P(d), U64(1), U64(1), ctypes.c_int(2), ctypes.byref(op))
+    with pytest.raises(MpcxError, match="NULL"):
+        ctx._call("mpcx_aby3_matmul_local_prepared", P(d), P(d), ctypes.c_int(0), None, U64(1), U64(0), U64(KEY01), U64(0),
+                  U64(KEY20), U64(0), P(d))
+    ctx._call("mpcx_aby3_operand_free", None)  # nothing to free: accepted
+    with pytest.raises(MpcxError, match="temp must be"):
+        ctx._call("mpcx_aby3_msb_round_pre_bits", P(ctx.empty(np.uint64, 8)), U64(1), U64(3), P(ctx.empty(np.uint32, 2)))
+    with pytest.raises(MpcxError, match="NULL"):
+        ctx._call("mpcx_d2h_bits", None, P(d), U64(5))
+    with pytest.raises(MpcxError, match="NULL"):
+        ctx._call("mpcx_h2d_u16", P(d), None, U64(5))
+    ctx._call("mpcx_h2d_bits", None, None, U64(0))  # empty payloads are no-ops
+    ctx._call("mpcx_d2h_u16", None, None, U64(0))
 
 
 @pytest.mark.parametrize("n", [1, 3, 13, 777, 5001])
