@@ -336,7 +336,6 @@ int mpcx_aby3_matmul_local_rows(mpcx_ctx *ctx, const int64_t *X0, const int64_t 
                                 uint64_t seed_next, uint64_t pop_next, uint64_t seed_prev, uint64_t pop_prev,
                                 int64_t *Z0) {
     MPCX_REQUIRE(X0 && X1 && Y0 && Y1 && Z0, "mpcx_aby3_matmul_local_rows: NULL operand");
-    MPCX_REQUIRE(rows && l && c, "mpcx_aby3_matmul_local_rows: empty shape");
     return aby3_matmul_impl(ctx, X0, X1, Y0, Y1, rows, l, c, 0, 0, row0 * c, seed_next, pop_next, seed_prev, pop_prev, Z0);
 }
 
@@ -344,7 +343,6 @@ int mpcx_aby3_matmul_local(mpcx_ctx *ctx, const int64_t *X0, const int64_t *X1, 
                            uint64_t r, uint64_t l, uint64_t c, int layout, uint64_t seed_next, uint64_t pop_next,
                            uint64_t seed_prev, uint64_t pop_prev, int64_t *Z0) {
     MPCX_REQUIRE(X0 && X1 && Y0 && Y1 && Z0, "mpcx_aby3_matmul_local: NULL operand");
-    MPCX_REQUIRE(r && l && c, "mpcx_aby3_matmul_local: empty shape");
     MPCX_REQUIRE(layout == 0 || layout == 1, "mpcx_aby3_matmul_local: layout must be 0 or 1");
     return aby3_matmul_impl(ctx, X0, X1, Y0, Y1, r, l, c, layout, layout, 0, seed_next, pop_next, seed_prev, pop_prev, Z0);
 }
@@ -389,7 +387,6 @@ int mpcx_aby3_matmul_local_prepared(mpcx_ctx *ctx, const int64_t *X0, const int6
                                     const mpcx_aby3_operand *Y, uint64_t rows, uint64_t row0, uint64_t seed_next,
                                     uint64_t pop_next, uint64_t seed_prev, uint64_t pop_prev, int64_t *Z0) {
     MPCX_REQUIRE(X0 && X1 && Y && Z0, "mpcx_aby3_matmul_local_prepared: NULL operand");
-    MPCX_REQUIRE(rows, "mpcx_aby3_matmul_local_prepared: empty shape");
     MPCX_REQUIRE(layoutX == 0 || layoutX == 1, "mpcx_aby3_matmul_local_prepared: layout must be 0 or 1");
     MPCX_REQUIRE(Y->device == ctx->device, "mpcx_aby3_matmul_local_prepared: the operand was prepared on device %d, the context "
                  "works on device %d", Y->device, ctx->device);

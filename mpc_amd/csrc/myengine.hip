@@ -140,7 +140,6 @@ extern "C" {
 int mpcx_my_beaver_dealer_matmul_rows(mpcx_ctx *ctx, uint64_t seed0, uint64_t seed1, uint64_t seedS, uint64_t r, uint64_t l,
                                       uint64_t c, uint64_t row0, uint64_t rows, int64_t *C0, int64_t *C1) {
     MPCX_REQUIRE(C0 && C1, "mpcx_my_beaver_dealer_matmul_rows: NULL pointer");
-    MPCX_REQUIRE(r && l && c && rows, "mpcx_my_beaver_dealer_matmul_rows: empty shape");
     MPCX_REQUIRE(row0 <= r && rows <= r - row0, "mpcx_my_beaver_dealer_matmul_rows: rows [%llu, +%llu) outside %llu rows",
                  (unsigned long long)row0, (unsigned long long)rows, (unsigned long long)r);
     const u64 na = r * l, nb = l * c, ma = rows * l, mc = rows * c;
@@ -160,14 +159,12 @@ int mpcx_my_beaver_dealer_matmul_rows(mpcx_ctx *ctx, uint64_t seed0, uint64_t se
 }
 int mpcx_my_beaver_dealer_matmul(mpcx_ctx *ctx, uint64_t seed0, uint64_t seed1, uint64_t seedS, uint64_t r, uint64_t l,
                                  uint64_t c, int64_t *C0, int64_t *C1) {
-    MPCX_REQUIRE(r && l && c, "mpcx_my_beaver_dealer_matmul: empty shape");
     return mpcx_my_beaver_dealer_matmul_rows(ctx, seed0, seed1, seedS, r, l, c, 0, r, C0, C1);
 }
 
 int mpcx_my_beaver_party_open_matmul(mpcx_ctx *ctx, const int64_t *X, const int64_t *Y, int layout, uint64_t seed2,
                                      uint64_t r, uint64_t l, uint64_t c, int64_t *ef_out) {
     MPCX_REQUIRE(X && Y && ef_out, "mpcx_my_beaver_party_open_matmul: NULL pointer");
-    MPCX_REQUIRE(r && l && c, "mpcx_my_beaver_party_open_matmul: empty shape");
     const u64 na = r * l, nb = l * c;
     Tmp t(ctx);
     MPCX_TRY(t.get(8 * (na + nb)));
@@ -183,7 +180,6 @@ int mpcx_my_beaver_party_finish_matmul_rows(mpcx_ctx *ctx, int party, uint64_t s
                                             uint64_t rows, int layoutZ, int64_t *Z) {
     MPCX_REQUIRE(party == 0 || party == 1, "mpcx_my_beaver_party_finish_matmul_rows: party %d", party);
     MPCX_REQUIRE(C && ef_own && ef_peer && Z, "mpcx_my_beaver_party_finish_matmul_rows: NULL pointer");
-    MPCX_REQUIRE(r && l && c && rows, "mpcx_my_beaver_party_finish_matmul_rows: empty shape");
     MPCX_REQUIRE(row0 <= r && rows <= r - row0, "mpcx_my_beaver_party_finish_matmul_rows: rows [%llu, +%llu) outside %llu rows",
                  (unsigned long long)row0, (unsigned long long)rows, (unsigned long long)r);
     const u64 na = r * l, nb = l * c, ma = rows * l, mc = rows * c;
@@ -199,7 +195,6 @@ int mpcx_my_beaver_party_finish_matmul_rows(mpcx_ctx *ctx, int party, uint64_t s
 int mpcx_my_beaver_party_finish_matmul(mpcx_ctx *ctx, int party, uint64_t seed2, const int64_t *C, const int64_t *ef_own,
                                        const int64_t *ef_peer, uint64_t r, uint64_t l, uint64_t c, int layoutZ,
                                        int64_t *Z) {
-    MPCX_REQUIRE(r && l && c, "mpcx_my_beaver_party_finish_matmul: empty shape");
     return mpcx_my_beaver_party_finish_matmul_rows(ctx, party, seed2, C, ef_own, ef_peer, r, l, c, 0, r, layoutZ, Z);
 }
 

@@ -399,6 +399,7 @@ static u64 positional_ws_bytes(int nparts, u64 r, u64 l, u64 c) {
 }
 
 u64 ring_gemm_ws_bytes(int nparts, u64 r, u64 l, u64 c) {
+    if (r == 0 || l == 0 || c == 0) return 0;
     if (ring_gemm_use_rns(nparts, r, l, c)) return ring_gemm_rns_ws_bytes(nparts, r, l, c);
     return positional_ws_bytes(nparts, r, l, c);
 }
@@ -406,9 +407,32 @@ u64 ring_gemm_ws_bytes(int nparts, u64 r, u64 l, u64 c) {
 static int ring_gemm_positional(mpcx_ctx *ctx, const GemmPart *parts, int nparts, u64 r, u64 l, u64 c, int layA, int layB,
                                 const i64 *add, const i64 *sub, i64 *Z, int layZ, int accumulate, void *ws);
 
+// the product over an empty contraction (l = 0): every entry is the empty sum, Z (+)= add - sub
+__global__ __launch_bounds__(256) void empty_sum_kernel(u64 r, u64 c, const u64 *__restrict__ add, const u64 *__restrict__ sub,
+                                                        u64 *__restrict__ Z, u64 ldr, u64 ldc, int accumulate) {
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < r * c; i += (u64)gridDim.x * 256) {
+        const u64 row = i / c, col = i - row * c, zi = row * ldr + col * ldc;
+        u64 v = accumulate ? Z[zi] : 0;
+        if (add) v += add[i];
+        if (sub) v -= sub[i];
+        Z[zi] = v;
+    }
+}
+
+// Matrices without rows or columns are legal operands of the engines (Eigen multiplies them: an empty result, or all
+// zeros over an empty contraction), so the protocol segments pass them through to here.
 int ring_gemm_parts(mpcx_ctx *ctx, const GemmPart *parts, int nparts, u64 r, u64 l, u64 c, int layA, int layB,
                     const i64 *add, const i64 *sub, i64 *Z, int layZ, int accumulate, const RnsPreB *pre) {
-    if (r && l && c && ring_gemm_use_rns(nparts, r, l, c))
+    if (r == 0 || c == 0) return 0;
+    if (l == 0) {
+        u64 blocks = ceil_div(r * c, 256);
+        if (blocks > 65536) blocks = 65536;
+        hipLaunchKernelGGL(empty_sum_kernel, dim3((u32)blocks), dim3(256), 0, ctx->stream, r, c, (const u64 *)add, (const u64 *)sub,
+                           (u64 *)Z, layZ ? (u64)1 : c, layZ ? r : (u64)1, accumulate);
+        MPCX_LAUNCH_CHECK();
+        return 0;
+    }
+    if (ring_gemm_use_rns(nparts, r, l, c))
         return ring_gemm_parts_rns(ctx, parts, nparts, r, l, c, layA, layB, add, sub, Z, layZ, accumulate, pre);
     MPCX_REQUIRE(r > 0 && l > 0 && c > 0, "ring gemm: empty operand (r=%llu l=%llu c=%llu)", (unsigned long long)r,
                  (unsigned long long)l, (unsigned long long)c);
@@ -553,6 +577,8 @@ uint64_t mpcx_ring_gemm_noalloc_bytes(uint64_t r, uint64_t l, uint64_t c) { retu
 int mpcx_ring_gemm_u64(mpcx_ctx *ctx, const int64_t *A, const int64_t *B, int64_t *C, uint64_t r, uint64_t l,
                        uint64_t c, int layoutA, int layoutB, int layoutC, int accumulate) {
     MPCX_REQUIRE(A && B && C, "mpcx_ring_gemm_u64: NULL operand");
+    MPCX_REQUIRE(r > 0 && l > 0 && c > 0, "ring gemm: empty operand (r=%llu l=%llu c=%llu)", (unsigned long long)r,
+                 (unsigned long long)l, (unsigned long long)c);
     GemmPart p{A, B, nullptr};
     return ring_gemm_parts(ctx, &p, 1, r, l, c, layoutA, layoutB, nullptr, nullptr, C, layoutC, accumulate);
 }

@@ -463,7 +463,6 @@ int mpcx_snn_beaver_dealer_matmul_rows(mpcx_ctx *ctx, uint64_t seedS, uint64_t r
                                        int64_t *C1) {
     MPCX_REQUIRE(A0 && A1 && C0 && C1, "mpcx_snn_beaver_dealer_matmul_rows: NULL pointer");
     MPCX_REQUIRE(!B0 == !B1, "mpcx_snn_beaver_dealer_matmul_rows: B0 and B1 go together");
-    MPCX_REQUIRE(r && l && c && rows, "mpcx_snn_beaver_dealer_matmul_rows: empty shape");
     MPCX_REQUIRE(row0 <= r && rows <= r - row0, "mpcx_snn_beaver_dealer_matmul_rows: rows [%llu, +%llu) outside %llu rows",
                  (unsigned long long)row0, (unsigned long long)rows, (unsigned long long)r);
     const u64 na = r * l, nb = l * c, ma = rows * l, mc = rows * c;
@@ -486,7 +485,6 @@ int mpcx_snn_beaver_dealer_matmul_rows(mpcx_ctx *ctx, uint64_t seedS, uint64_t r
 int mpcx_snn_beaver_dealer_matmul(mpcx_ctx *ctx, uint64_t seedS, uint64_t r, uint64_t l, uint64_t c, int64_t *msg0,
                                   int64_t *msg1) {
     MPCX_REQUIRE(msg0 && msg1, "mpcx_snn_beaver_dealer_matmul: NULL pointer");
-    MPCX_REQUIRE(r && l && c, "mpcx_snn_beaver_dealer_matmul: empty shape");
     const u64 na = r * l, nb = l * c;
     return mpcx_snn_beaver_dealer_matmul_rows(ctx, seedS, r, l, c, 0, r, msg0, msg1, msg0 + na, msg1 + na, msg0 + na + nb,
                                               msg1 + na + nb);
@@ -495,7 +493,6 @@ int mpcx_snn_beaver_dealer_matmul(mpcx_ctx *ctx, uint64_t seedS, uint64_t r, uin
 int mpcx_snn_beaver_party_open_matmul(mpcx_ctx *ctx, const int64_t *X, const int64_t *Y, int layout,
                                       const int64_t *triple, uint64_t r, uint64_t l, uint64_t c, int64_t *ef_out) {
     MPCX_REQUIRE(X && Y && triple && ef_out, "mpcx_snn_beaver_party_open_matmul: NULL pointer");
-    MPCX_REQUIRE(r && l && c, "mpcx_snn_beaver_party_open_matmul: empty shape");
     const u64 na = r * l, nb = l * c;
     const u64 *x = (const u64 *)X, *y = (const u64 *)Y, *t = (const u64 *)triple;
     u64 *o = (u64 *)ef_out;
@@ -515,7 +512,6 @@ int mpcx_snn_beaver_party_finish_matmul(mpcx_ctx *ctx, int party, const int64_t 
                                         int64_t *Z) {
     MPCX_REQUIRE(party == 0 || party == 1, "mpcx_snn_beaver_party_finish_matmul: party %d", party);
     MPCX_REQUIRE(triple && ef_own && ef_peer && Z, "mpcx_snn_beaver_party_finish_matmul: NULL pointer");
-    MPCX_REQUIRE(r && l && c, "mpcx_snn_beaver_party_finish_matmul: empty shape");
     const u64 na = r * l, nb = l * c;
     const u64 gemm_bytes = ring_gemm_ws_bytes(2, r, l, c);
     void *ws;

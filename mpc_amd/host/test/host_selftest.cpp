@@ -474,6 +474,82 @@ static void snn_additions_party(InProcHub *hub, size_t p) {
     }
 }
 
+// every method on empty vectors and on matrices without rows or without columns: the reference's loops simply do not
+// run, the results are empty, the rounds still take place (all three parties stay in step)
+static void empty_inputs_party(InProcHub *hub, size_t p) {
+    InProcMessenger msgr(hub, p);
+    {
+        ABY3Engine e(&msgr, p);
+        VecI64 X, R;
+        array<VecI64, 2> Xj, Gj, Pj, Cj, Tj, Vj;
+        array<vecbool, 2> Zj, Bj;
+        vecbool B, Bo;
+        e.share(X, Xj);
+        e.add_prepare(Xj, Gj, Pj);
+        e.msb(Gj, Pj, Zj);
+        e.bit_inject(Xj, Zj, Cj);
+        e.trunc(Xj, Tj, 16);
+        e.vector_mul(Xj, Xj, Vj);
+        e.relu(Xj, Cj);
+        e.reveal(Cj, R);
+        e.share_bools(B, Bj);
+        e.vecbool_mul(Bj, Bj, Zj);
+        e.reveal_bools(Zj, Bo);
+        e.reveal_bits(Xj, R);
+        CHECK(R.size() == 0 && Bo.size() == 0 && Cj[0].size() == 0 && Zj[1].size() == 0);
+        for (size_t shape = 0; shape < 3; shape++) {
+            const size_t r = shape == 0 ? 0 : 3, l = shape == 1 ? 0 : 4, c = shape == 2 ? 0 : 5;
+            MatrixXl A(r, l), Bm(l, c), P;
+            for (size_t i = 0; i < r; i++)
+                for (size_t j = 0; j < l; j++) A(i, j) = (int64_t)(i + 2 * j + 1);
+            for (size_t i = 0; i < l; i++)
+                for (size_t j = 0; j < c; j++) Bm(i, j) = (int64_t)(3 * i + j + 1);
+            array<MatrixXl, 2> Aj, Bmj, Pj2;
+            e.share_matrix(A, Aj);
+            e.share_matrix(Bm, Bmj);
+            e.matrix_mul(Aj, Bmj, Pj2);
+            e.reveal_matrix(Pj2, P);
+            CHECK((size_t)P.rows() == r && (size_t)P.cols() == c);
+            for (size_t i = 0; i < r; i++)
+                for (size_t j = 0; j < c; j++) CHECK(P(i, j) == 0); // l = 0: the empty sum
+        }
+    }
+    {
+        SecurennEngine e(&msgr, p);
+        SecurennEngine::Words X, Xs, Y, R;
+        SecurennEngine::Bits Bo;
+        e.share(X, Xs);
+        e.vector_mul(Xs, Xs, Y);
+        e.msb(Xs, Y);
+        e.relu(Xs, Y);
+        e.shareConvert(Xs, Y);
+        e.msb_L_1(Xs, Y);
+        e.reveal(Y, R);
+        vector<zpshare> xb;
+        e.privateCompare(xb, Bo, X, Bo);
+        CHECK(R.size() == 0 && Bo.size() == 0);
+        MatrixXl A(0, 4), Bm(4, 5), Z, P;
+        e.matrix_mul(A, Bm, Z);
+        e.reveal_matrix(Z, P);
+        CHECK(P.rows() == 0 && P.cols() == 5);
+    }
+    {
+        MyEngine e(&msgr, p);
+        VecI64 X, Xs, Z, R;
+        vecbool A;
+        e.share(X, Xs);
+        e.msb(Xs, A);
+        e.bit_inject(Xs, A, Z);
+        e.vector_mul(Xs, Xs, Z);
+        e.reveal(Z, R);
+        CHECK(R.size() == 0 && A.size() == 0);
+        MatrixXl M(0, 4), Bm(4, 5), Zm, P;
+        e.matrix_mul(M, Bm, Zm);
+        e.reveal_matrix(Zm, P);
+        CHECK(P.rows() == 0 && P.cols() == 5);
+    }
+}
+
 template <class F> static void run3(F party) {
     InProcHub hub;
     std::thread t0(party, &hub, 0), t1(party, &hub, 1), t2(party, &hub, 2);
@@ -513,6 +589,7 @@ int main() {
     run3(my_party);
     run3(aby3_additions_party);
     run3(snn_additions_party);
+    run3(empty_inputs_party);
     if (failures.load()) {
         printf("host_selftest: %d check(s) FAILED\n", failures.load());
         return 1;

@@ -168,7 +168,8 @@ def test_aby3_matmul_config1_golden(gpu, orc):
 
 
 @pytest.mark.parametrize("r,l,c,layout", [(5, 4, 3, 0), (5, 4, 3, 1), (200, 200, 200, 0), (130, 257, 66, 1),
-                                           (520, 140, 515, 0), (512, 512, 512, 1)])
+                                           (520, 140, 515, 0), (512, 512, 512, 1),
+                                           (5, 0, 3, 0), (5, 0, 3, 1), (0, 4, 3, 0), (5, 4, 0, 1)])  # empty contraction / result
 def test_aby3_matmul_protocol_parity(gpu, orc, r, l, c, layout):
     rng = np.random.default_rng(r + l + c)
     X, Y = rnd(rng, r * l), rnd(rng, l * c)

@@ -38,7 +38,8 @@ def rnd(rng, n):
     return rng.integers(-2 ** 63, 2 ** 63, int(n), dtype=np.int64)
 
 
-@pytest.mark.parametrize("r,l,c,layout", [(3, 4, 5, 0), (9, 11, 10, 1), (128, 784, 128, 0), (200, 200, 200, 0), (130, 257, 66, 1)])
+@pytest.mark.parametrize("r,l,c,layout", [(3, 4, 5, 0), (9, 11, 10, 1), (128, 784, 128, 0), (200, 200, 200, 0), (130, 257, 66, 1),
+                                           (3, 0, 5, 0), (0, 4, 5, 1), (3, 4, 0, 0)])  # empty contraction / result
 def test_my_matmul_parity(gpu, orm, r, l, c, layout):
     """Includes shapes whose buffer offsets lie far beyond BUFF_NUM (extended-buffer semantics)."""
     rng = np.random.default_rng(r * 31 + c)
@@ -161,8 +162,10 @@ def test_my_errors_and_device_pool(gpu):
                 ("out", np.int64, 1))
     with pytest.raises(MpcxError, match="range outside"):
         gpu._go("my_beaver_dealer_vecmul", KEY20, KEY12, KEYS, 4, 3, 2, ("out", np.int64, 2), ("out", np.int64, 2))
-    with pytest.raises(MpcxError, match="empty shape"):
-        gpu._go("my_beaver_dealer_matmul", KEY20, KEY12, KEYS, 0, 1, 1, ("out", np.int64, 1), ("out", np.int64, 1))
+    with pytest.raises(MpcxError, match="outside 2 rows"):  # rows [1, 3) of a product with two rows
+        gpu._go("my_beaver_dealer_matmul_rows", KEY20, KEY12, KEYS, 2, 1, 1, 1, 2, ("out", np.int64, 2), ("out", np.int64, 2))
+    # a product without rows is legal (Eigen multiplies empty matrices): nothing is written
+    gpu._go("my_beaver_dealer_matmul", KEY20, KEY12, KEYS, 0, 1, 1, ("out", np.int64, 1), ("out", np.int64, 1))
     ctx = gpu.ctx
     a = ctx.empty(np.int64, 1000)
     p = a.ptr

@@ -124,7 +124,8 @@ def test_snn_matmul_config_golden(gpu, orc):
     assert cks(pr.snn_reveal(wg, Zg)) == g["Z_plain"]
 
 
-@pytest.mark.parametrize("r,l,c,layout", [(3, 4, 5, 0), (3, 4, 5, 1), (128, 784, 128, 0), (128, 128, 10, 1), (200, 200, 200, 0)])
+@pytest.mark.parametrize("r,l,c,layout", [(3, 4, 5, 0), (3, 4, 5, 1), (128, 784, 128, 0), (128, 128, 10, 1), (200, 200, 200, 0),
+                                           (3, 0, 5, 0), (0, 4, 5, 1), (3, 4, 0, 0)])  # empty contraction / result
 def test_snn_matmul_protocol_parity(gpu, orc, r, l, c, layout):
     """Includes the MLP layer shapes (beyond BUFF_NUM: extended-buffer semantics) and 200x200 of the benchmark."""
     rng = np.random.default_rng(r * 7 + c)
